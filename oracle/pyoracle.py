@@ -1,0 +1,239 @@
+"""ctypes bindings for the CPU checkers under oracle/.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product path (mcmcpp_amd, libmcmcpp_hip.so) never does.
+
+  Oracle      this repo's C restatement (oracle/liboracle.so, built by oracle/Makefile)
+  Reference   the reference itself compiled from /root/reference (oracle/_ref/libmcmcpp_ref.so);
+              present only where it was prebuilt in the build container.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+F64, F32 = 0, 1
+CALC_ISO_GAUSSIAN, CALC_DENSE_GAUSSIAN, CALC_ROSENBROCK, CALC_SKEWED_GAUSSIAN_2D = 0, 1, 2, 3
+MODE_SEQUENTIAL, MODE_COUNTER = 0, 1
+
+
+def np_dtype(dtype):
+    return np.float64 if dtype == F64 else np.float32
+
+
+class _Config(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("num_walkers", C.c_int32), ("num_params", C.c_int32),
+                ("calc_id", C.c_int32), ("calc_params", C.c_void_p), ("calc_params_len", C.c_int32),
+                ("reserved", C.c_int32), ("seed", C.c_uint64), ("stream", C.c_uint64)]
+
+
+class _Pcg64(C.Structure):
+    _fields_ = [("state_hi", C.c_uint64), ("state_lo", C.c_uint64),
+                ("inc_hi", C.c_uint64), ("inc_lo", C.c_uint64)]
+
+
+def build(force=False):
+    """(Re)build liboracle.so and, when /root/reference is present, _ref/libmcmcpp_ref.so."""
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
+            for f in ("stretch_oracle.c", "stretch_oracle_typed.inc", "stretch_oracle.h")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref = os.path.join(_HERE, "_ref", "libmcmcpp_ref.so")
+    if os.path.exists("/root/reference/MCMCpp/EnsembleSampler.h") and (
+            force or not os.path.exists(ref)
+            or os.path.getmtime(os.path.join(_HERE, "ref_driver.cpp")) > os.path.getmtime(ref)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.so_create.argtypes = [C.POINTER(_Config), C.POINTER(C.c_void_p)]
+        L.so_destroy.argtypes = [C.c_void_p]
+        L.so_destroy.restype = None
+        L.so_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.so_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("so_half_steps_done", "so_near_ties", "so_redraws"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = C.c_uint64
+        L.so_calc_logp.argtypes = [C.POINTER(_Config), C.c_void_p, C.c_void_p]
+        L.so_pcg64_seed.argtypes = [C.POINTER(_Pcg64), C.c_uint64, C.c_uint64]
+        L.so_pcg64_seed.restype = None
+        L.so_pcg64_next.argtypes = [C.POINTER(_Pcg64)]
+        L.so_pcg64_next.restype = C.c_uint64
+        L.so_pcg64_advance.argtypes = [C.POINTER(_Pcg64), C.c_uint64, C.c_uint64]
+        L.so_pcg64_advance.restype = None
+        L.so_pcg64_jump_coeffs.argtypes = [C.c_uint64] * 4 + [C.POINTER(C.c_uint64 * 2)] * 2
+        L.so_pcg64_jump_coeffs.restype = None
+        L.so_canonical_f64.argtypes = [C.c_uint64]
+        L.so_canonical_f64.restype = C.c_double
+        L.so_canonical_f32.argtypes = [C.c_uint64]
+        L.so_canonical_f32.restype = C.c_float
+        L.so_init_positions.argtypes = [C.c_int32, C.c_int64, C.c_uint64, C.c_void_p]
+        L.so_init_positions.restype = None
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Pcg64:
+    """pcg64 engine of the oracle (known-answer tests)."""
+
+    def __init__(self, seed, stream=0):
+        self.g = _Pcg64()
+        lib().so_pcg64_seed(C.byref(self.g), seed & (2**64 - 1), stream & (2**64 - 1))
+
+    def next(self):
+        return lib().so_pcg64_next(C.byref(self.g))
+
+    def advance(self, delta):
+        lib().so_pcg64_advance(C.byref(self.g), (delta >> 64) & (2**64 - 1), delta & (2**64 - 1))
+
+    @property
+    def state(self):
+        return (self.g.state_hi << 64) | self.g.state_lo
+
+    @property
+    def inc(self):
+        return (self.g.inc_hi << 64) | self.g.inc_lo
+
+
+def jump_coeffs(inc, delta):
+    m = (C.c_uint64 * 2)()
+    p = (C.c_uint64 * 2)()
+    M = 2**64 - 1
+    lib().so_pcg64_jump_coeffs((inc >> 64) & M, inc & M, (delta >> 64) & M, delta & M, C.byref(m), C.byref(p))
+    return (m[0] << 64) | m[1], (p[0] << 64) | p[1]
+
+
+def init_positions(dtype, W, D, salt=0):
+    out = np.empty((W, D), dtype=np_dtype(dtype))
+    lib().so_init_positions(dtype, W * D, salt, _ptr(out))
+    return out
+
+
+class Oracle:
+    """The CPU restatement of EnsembleSampler + StretchMove."""
+
+    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64):
+        self.W, self.D, self.dtype = W, D, dtype
+        self.np_t = np_dtype(dtype)
+        self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
+        self.cfg = _Config(dtype, W, D, calc_id, _ptr(self.params), 0 if self.params is None else self.params.size,
+                           0, seed & (2**64 - 1), stream & (2**64 - 1))
+        self.h = C.c_void_p()
+        rc = lib().so_create(C.byref(self.cfg), C.byref(self.h))
+        if rc:
+            raise ValueError("so_create failed: %d" % rc)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().so_destroy(self.h)
+            self.h = None
+
+    def logp(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=self.np_t).reshape(-1, self.D)
+        out = np.empty(pos.shape[0], dtype=self.np_t)
+        for i in range(pos.shape[0]):
+            rc = lib().so_calc_logp(C.byref(self.cfg), _ptr(pos[i]), out[i:i + 1].ctypes.data_as(C.c_void_p))
+            assert rc == 0
+        return out
+
+    def set_state(self, pos, logp):
+        pos = np.ascontiguousarray(pos, dtype=self.np_t)
+        logp = np.ascontiguousarray(logp, dtype=self.np_t)
+        assert pos.size == self.W * self.D and logp.size == self.W
+        assert lib().so_set_state(self.h, _ptr(pos), _ptr(logp)) == 0
+
+    def run(self, n_saved, interval=1, save_chain=True, mode=MODE_SEQUENTIAL, threads=1):
+        chain = np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None
+        acc = np.zeros(n_saved * interval, dtype=np.uint32)
+        rc = lib().so_run(self.h, n_saved, interval, _ptr(chain), _ptr(acc), mode, threads)
+        if rc:
+            raise ValueError("so_run failed: %d" % rc)
+        return chain, acc
+
+    def get_state(self):
+        pos = np.empty((self.W, self.D), dtype=self.np_t)
+        logp = np.empty(self.W, dtype=self.np_t)
+        nacc = np.empty(self.W, dtype=np.uint32)
+        assert lib().so_get_state(self.h, _ptr(pos), _ptr(logp), _ptr(nacc)) == 0
+        return pos, logp, nacc
+
+    @property
+    def near_ties(self):
+        return lib().so_near_ties(self.h)
+
+    @property
+    def redraws(self):
+        return lib().so_redraws(self.h)
+
+
+# ---- the reference itself (only where oracle/_ref was prebuilt) ------------------------------------
+
+_ref = None
+
+
+def reference_available():
+    build()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libmcmcpp_ref.so"))
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        build()
+        R = C.CDLL(os.path.join(_HERE, "_ref", "libmcmcpp_ref.so"))
+        R.ref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
+                              C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        R.ref_skewed_initial_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
+        R.ref_skewed_initial_values.restype = None
+        _ref = R
+    return _ref
+
+
+def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_call, slicing=1, want_chain=True,
+                  threads=0, dtype=F64):
+    """Run MCMC::EnsembleSampler (threads=0) or ParallelEnsembleSampler (threads>=1) of the reference.
+
+    Returns dict(chain[(stored, W, D)] incl. step 0 = initial placement, accepted[n_calls], total[n_calls],
+    stored, seconds, fraction)."""
+    t = np_dtype(dtype)
+    pos = np.ascontiguousarray(pos, dtype=t)
+    logp = np.ascontiguousarray(logp, dtype=t)
+    prm = None if params is None else np.ascontiguousarray(params, dtype=t).ravel()
+    cap = 1 + n_calls * steps_per_call if want_chain else 0
+    chain = np.zeros((cap, W, D), dtype=t) if want_chain else None
+    acc = np.zeros(n_calls, dtype=np.uint64)
+    tot = np.zeros(n_calls, dtype=np.uint64)
+    stored = C.c_int(0)
+    secs = C.c_double(0)
+    frac = C.c_double(0)
+    rc = ref_lib().ref_run(dtype, threads, W, D, calc_id, _ptr(prm), seed, _ptr(pos), _ptr(logp), n_calls,
+                           steps_per_call, slicing, _ptr(chain), cap, _ptr(acc), _ptr(tot), C.byref(stored),
+                           C.byref(secs), C.byref(frac))
+    if rc < 0:
+        raise ValueError("ref_run failed: %d" % rc)
+    return dict(chain=chain, accepted=acc, total=tot, stored=stored.value, seconds=secs.value,
+                fraction=frac.value, chain_full=(rc == 1))
+
+
+def reference_skewed_initial_values(W=320, eps=0.13, extra_run_number=53):
+    init = np.empty((W, 2), dtype=np.float64)
+    aux = np.empty(W, dtype=np.float64)
+    ref_lib().ref_skewed_initial_values(_ptr(init), _ptr(aux), W, eps, extra_run_number)
+    return init, aux

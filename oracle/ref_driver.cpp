@@ -1,0 +1,170 @@
+/*
+ * ref_driver.cpp -- drives the REFERENCE sampler (headers compiled from /root/reference where they
+ * lie; nothing of the reference is copied into this repo) so that its outputs can pin the oracle and
+ * serve as the CPU baseline.  TEST INFRASTRUCTURE ONLY; built by oracle/Makefile into
+ * oracle/_ref/libmcmcpp_ref.so (git-ignored, never part of the product path).
+ *
+ * It instantiates the reference's own
+ *   MCMC::EnsembleSampler<T, MCMC::Mover::StretchMove<T, Calculator>>          (EnsembleSampler.h:39)
+ *   MCMC::ParallelEnsembleSampler<T, ...>                                      (ParallelEnsembleSampler.h:78)
+ * with this repo's Calculators (include/MCMCpp/Device/Calculators.h -- any class with
+ * calcLogPostProb(T*) is a legal reference Calculator) and with the reference's SkewedGaussianTwoDim.
+ */
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <random>
+
+// pcg-cpp: un-vendored submodule of the reference; the image's copy lives in namespace arrow_vendored.
+#include PCG_HEADER
+using arrow_vendored::pcg32;
+using arrow_vendored::pcg64;
+
+#include "EnsembleSampler.h"
+#include "Movers/StretchMove.h"
+#include "ParallelEnsembleSampler.h"
+#include "Common/SkewedGaussian.h"
+
+#include "../include/MCMCpp/Device/Calculators.h"
+
+namespace
+{
+template <class T, class Calc>
+int runSequential(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
+                  int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+                  unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
+                  double* seconds)
+{
+    typedef MCMC::Mover::StretchMove<T, Calc> MoverType;
+    MoverType mover(D, seed, calc);
+    MCMC::EnsembleSampler<T, MoverType> sampler(seed, W, D, mover);
+    if (slicing > 1) sampler.setSlicingMode(true, slicing);
+    sampler.setInitialWalkerPos(const_cast<T*>(initPos), const_cast<T*>(initLogp));
+    bool ok = true;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int c = 0; c < nCalls; ++c)
+    {
+        ok = sampler.runMCMC(stepsPerCall) && ok;
+        if (acceptedAfterCall) acceptedAfterCall[c] = sampler.getAcceptedSteps();
+        if (totalAfterCall) totalAfterCall[c] = sampler.getTotalSteps();
+    }
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (storedSteps) *storedSteps = sampler.getStoredSteps();
+    if (chainOut)
+    {
+        long long k = 0;
+        auto end = sampler.getStepIttEnd();
+        for (auto it = sampler.getStepIttBegin(); it != end && k < chainCapacitySteps; ++it, ++k)
+            std::memcpy(chainOut + static_cast<size_t>(k) * W * D, *it, sizeof(T) * static_cast<size_t>(W) * D);
+    }
+    return ok ? 0 : 1;
+}
+
+template <class T, class Calc>
+int runParallel(Calc& calc, int threads, int W, int D, int seed, const T* initPos, const T* initLogp, int nSteps,
+                double* seconds, double* acceptanceFraction)
+{
+    typedef MCMC::Mover::StretchMove<T, Calc> MoverType;
+    MoverType mover(D, seed, calc);
+    MCMC::ParallelEnsembleSampler<T, MoverType> sampler(seed, threads, W, D, mover);
+    sampler.setInitialWalkerPos(const_cast<T*>(initPos), const_cast<T*>(initLogp));
+    auto t0 = std::chrono::steady_clock::now();
+    bool ok = sampler.runMCMC(nSteps);
+    auto t1 = std::chrono::steady_clock::now();
+    if (seconds) *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (acceptanceFraction) *acceptanceFraction = static_cast<double>(sampler.getAcceptanceFraction());
+    return ok ? 0 : 1;
+}
+
+template <class T>
+int dispatch(int calcId, int threads, int W, int D, const T* params, int seed, const T* initPos, const T* initLogp,
+             int nCalls, int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+             unsigned long long* acc, unsigned long long* tot, int* stored, double* seconds, double* fraction)
+{
+#define MCMCPP_REF_GO(CALC)                                                                                        \
+    if (threads <= 0)                                                                                              \
+        return runSequential<T>(CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut,      \
+                                chainCapacitySteps, acc, tot, stored, seconds);                                    \
+    return runParallel<T>(CALC, threads, W, D, seed, initPos, initLogp, nCalls * stepsPerCall, seconds, fraction)
+    switch (calcId)
+    {
+    case MCMC::Device::IsoGaussianId:
+    {
+        MCMC::Device::IsoGaussian<T> c(D);
+        MCMCPP_REF_GO(c);
+    }
+    case MCMC::Device::DenseGaussianId:
+    {
+        MCMC::Device::DenseGaussian<T> c(D, params);
+        MCMCPP_REF_GO(c);
+    }
+    case MCMC::Device::RosenbrockId:
+    {
+        MCMC::Device::Rosenbrock<T> c(D, params[0], params[1], params[2]);
+        MCMCPP_REF_GO(c);
+    }
+    case MCMC::Device::SkewedGaussian2DId:
+    {
+        SkewedGaussianTwoDim<T> c(params[0]);  // the reference's own test Calculator
+        MCMCPP_REF_GO(c);
+    }
+    case 103:
+    {
+        MCMC::Device::SkewedGaussian2D<T> c(params[0]);  // this repo's restatement of it
+        MCMCPP_REF_GO(c);
+    }
+    default: return -6;
+    }
+#undef MCMCPP_REF_GO
+}
+}  // namespace
+
+extern "C"
+{
+/* threads <= 0: MCMC::EnsembleSampler; threads >= 1: MCMC::ParallelEnsembleSampler (timing only:
+ * it is non-deterministic above one thread, ParallelEnsembleSampler.h:71-76).
+ * dtype 0 = double, 1 = float.  chain_out holds up to chain_capacity_steps steps of W*D values
+ * (chain step 0 is the initial placement, EnsembleSampler.h:228-229). */
+int ref_run(int dtype, int threads, int W, int D, int calc_id, const void* params, int seed, const void* init_pos,
+            const void* init_logp, int n_calls, int steps_per_call, int slicing, void* chain_out,
+            long long chain_capacity_steps, unsigned long long* accepted_after_call,
+            unsigned long long* total_after_call, int* stored_steps, double* seconds, double* fraction)
+{
+    if (dtype == 0)
+        return dispatch<double>(calc_id, threads, W, D, static_cast<const double*>(params), seed,
+                                static_cast<const double*>(init_pos), static_cast<const double*>(init_logp), n_calls,
+                                steps_per_call, slicing, static_cast<double*>(chain_out), chain_capacity_steps,
+                                accepted_after_call, total_after_call, stored_steps, seconds, fraction);
+    return dispatch<float>(calc_id, threads, W, D, static_cast<const float*>(params), seed,
+                           static_cast<const float*>(init_pos), static_cast<const float*>(init_logp), n_calls,
+                           steps_per_call, slicing, static_cast<float*>(chain_out), chain_capacity_steps,
+                           accepted_after_call, total_after_call, stored_steps, seconds, fraction);
+}
+
+/* Initial walker placement of the reference's SkewedGaussian/StretchMove test
+ * (test/sequential/SkewedGaussian/StretchMove/src/main.cpp:141-205): pcg32(extraRunNumber) feeding four
+ * std::normal_distribution<double> in a 16-walker pattern.  Restated compactly (the draw order is
+ * row-major over the 4x4 pattern) so that the fixture can be generated; the arrays it returns are
+ * stored in tests/golden/ because libstdc++'s normal_distribution is implementation-defined. */
+void ref_skewed_initial_values(double* init_vals, double* aux_vals, int num_walkers, double eps, int extra_run_number)
+{
+    const double averages[2] = {3.1, -3.5};
+    const double deviations[2] = {3.3, 4.1};
+    pcg32 engine(extra_run_number);
+    std::normal_distribution<double> nd[4] = {std::normal_distribution<double>(averages[0], deviations[0]),
+                                              std::normal_distribution<double>(averages[1], deviations[1]),
+                                              std::normal_distribution<double>(averages[0], deviations[1]),
+                                              std::normal_distribution<double>(averages[1], deviations[0])};
+    SkewedGaussianTwoDim<double> likelihood(eps);
+    for (int i = 0; i < num_walkers; i += 16)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+            {
+                const int w = i + 4 * a + b;
+                init_vals[2 * w] = nd[a](engine);
+                init_vals[2 * w + 1] = nd[b](engine);
+                aux_vals[w] = likelihood.calcLogPostProb(init_vals + 2 * w);
+            }
+}
+}

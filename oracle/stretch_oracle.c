@@ -1,0 +1,293 @@
+/*
+ * stretch_oracle.c -- CPU restatement of the reference's stretch-move ensemble step.
+ * TEST INFRASTRUCTURE ONLY (see stretch_oracle.h).  Build: oracle/Makefile (-O2 -ffp-contract=off).
+ *
+ * Every function names the reference lines it follows (paths relative to /root/reference).
+ */
+#include "stretch_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+
+/* ---- pcg64 = setseq_xsl_rr_128_64 (imneme/pcg-cpp, call site MCMCpp/Utility/MultiSampler.h:120) -- */
+
+/* default 128-bit LCG multiplier of pcg-cpp: 2549297995355413924 * 2^64 + 4865540595714422341 */
+static u128 pcg_mult(void) { return ((u128)2549297995355413924ULL << 64) | 4865540595714422341ULL; }
+
+static u128 mk128(uint64_t hi, uint64_t lo) { return ((u128)hi << 64) | lo; }
+
+/* engine(state, stream): inc = (stream << 1) | 1; state = (seed + inc) * M + inc
+ * (MultiSampler.h:54 -> pcg engine::seed -> engine ctor -> bump) */
+void so_pcg64_seed(so_pcg64* g, uint64_t seed, uint64_t stream)
+{
+    u128 inc = (((u128)stream) << 1) | 1u;
+    u128 st = ((u128)seed + inc) * pcg_mult() + inc;
+    g->state_hi = (uint64_t)(st >> 64);
+    g->state_lo = (uint64_t)st;
+    g->inc_hi = (uint64_t)(inc >> 64);
+    g->inc_lo = (uint64_t)inc;
+}
+
+/* XSL-RR 128 -> 64 output of the state AFTER the LCG step (output_previous == false for 128-bit
+ * state): rot = s >> 122, x = hi ^ lo, rotr64(x, rot) */
+static uint64_t pcg_output(u128 s)
+{
+    uint64_t x = (uint64_t)(s >> 64) ^ (uint64_t)s;
+    unsigned rot = (unsigned)(s >> 122);
+    return (x >> rot) | (x << ((-rot) & 63u));
+}
+
+uint64_t so_pcg64_next(so_pcg64* g)
+{
+    u128 s = mk128(g->state_hi, g->state_lo) * pcg_mult() + mk128(g->inc_hi, g->inc_lo);
+    g->state_hi = (uint64_t)(s >> 64);
+    g->state_lo = (uint64_t)s;
+    return pcg_output(s);
+}
+
+/* Brown, "Random number generation with arbitrary strides": coefficients of `delta` LCG steps */
+static void jump_coeffs(u128 inc, u128 delta, u128* mult_out, u128* plus_out)
+{
+    u128 cur_mult = pcg_mult(), cur_plus = inc, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+        if (delta & 1u) {
+            acc_mult *= cur_mult;
+            acc_plus = acc_plus * cur_mult + cur_plus;
+        }
+        cur_plus = (cur_mult + 1u) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1;
+    }
+    *mult_out = acc_mult;
+    *plus_out = acc_plus;
+}
+
+void so_pcg64_jump_coeffs(uint64_t inc_hi, uint64_t inc_lo, uint64_t delta_hi, uint64_t delta_lo,
+                          uint64_t mult_out[2], uint64_t plus_out[2])
+{
+    u128 m, p;
+    jump_coeffs(mk128(inc_hi, inc_lo), mk128(delta_hi, delta_lo), &m, &p);
+    mult_out[0] = (uint64_t)(m >> 64);
+    mult_out[1] = (uint64_t)m;
+    plus_out[0] = (uint64_t)(p >> 64);
+    plus_out[1] = (uint64_t)p;
+}
+
+void so_pcg64_advance(so_pcg64* g, uint64_t delta_hi, uint64_t delta_lo)
+{
+    u128 m, p;
+    jump_coeffs(mk128(g->inc_hi, g->inc_lo), mk128(delta_hi, delta_lo), &m, &p);
+    u128 s = m * mk128(g->state_hi, g->state_lo) + p;
+    g->state_hi = (uint64_t)(s >> 64);
+    g->state_lo = (uint64_t)s;
+}
+
+/* libstdc++ 11 generate_canonical<double,53>(pcg64) (bits/random.tcc:3345-3380): one 64-bit draw,
+ * u = double(r) [round to nearest] / 2^64, clamped below 1 */
+double so_canonical_f64(uint64_t r)
+{
+    double u = (double)r / 18446744073709551616.0;
+    if (u >= 1.0) u = nextafter(1.0, 0.0);
+    return u;
+}
+
+float so_canonical_f32(uint64_t r)
+{
+    float u = (float)r / 18446744073709551616.0f;
+    if (u >= 1.0f) u = nextafterf(1.0f, 0.0f);
+    return u;
+}
+
+/* ---- initial positions (this repo's synthetic workload) --------------------------- */
+
+static uint64_t splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}
+
+void so_init_positions(int32_t dtype, int64_t count, uint64_t salt, void* out)
+{
+    for (int64_t k = 0; k < count; ++k) {
+        uint64_t h = splitmix64((uint64_t)k + salt * 0x632BE59BD9B4E019ULL);
+        double u = (double)(h >> 11) * (1.0 / 9007199254740992.0); /* top 53 bits * 2^-53 */
+        double x = 4.0 * u - 2.0;
+        if (dtype == SO_F64)
+            ((double*)out)[k] = x;
+        else
+            ((float*)out)[k] = (float)x;
+    }
+}
+
+/* ---- sampler ------------------------------------------------------------------------------------ */
+
+struct so_sampler {
+    so_config cfg;
+    void* params;      /* private copy of calc_params */
+    void* pos;         /* [W][D] */
+    void* logp;        /* [W] */
+    uint32_t* n_accept; /* [W] accepted proposals since set_state (initial placement not counted) */
+    so_pcg64 eng0;     /* engine right after seeding: draw 0 is its next output */
+    uint64_t half_steps;
+    uint64_t near_ties;
+    uint64_t redraws;
+};
+
+#define REAL double
+#define SFX(n) n##_f64
+#define LOG(x) log(x)
+#define FMA(a, b, c) fma(a, b, c)
+#define FABS(x) fabs(x)
+#define CANON(r) so_canonical_f64(r)
+#define TIE_EPS 1e-12
+#include "stretch_oracle_typed.inc"
+#undef REAL
+#undef SFX
+#undef LOG
+#undef FMA
+#undef FABS
+#undef CANON
+#undef TIE_EPS
+
+#define REAL float
+#define SFX(n) n##_f32
+#define LOG(x) logf(x)
+#define FMA(a, b, c) fmaf(a, b, c)
+#define FABS(x) fabsf(x)
+#define CANON(r) so_canonical_f32(r)
+#define TIE_EPS 6e-7f
+#include "stretch_oracle_typed.inc"
+#undef REAL
+#undef SFX
+#undef LOG
+#undef FMA
+#undef FABS
+#undef CANON
+#undef TIE_EPS
+
+static size_t elem_size(int dtype) { return dtype == SO_F64 ? sizeof(double) : sizeof(float); }
+
+static int check_cfg(const so_config* c)
+{
+    if (!c) return -1;
+    if (c->dtype != SO_F64 && c->dtype != SO_F32) return -2;
+    if (c->num_params < 1) return -3;
+    /* EnsembleSampler.h:207-208: even walker count, more than 2*D walkers */
+    if (c->num_walkers < 2 || (c->num_walkers & 1) || c->num_walkers <= 2 * c->num_params) return -4;
+    switch (c->calc_id) {
+    case SO_CALC_ISO_GAUSSIAN: break;
+    case SO_CALC_DENSE_GAUSSIAN:
+        if (!c->calc_params || c->calc_params_len != c->num_params * c->num_params) return -5;
+        break;
+    case SO_CALC_ROSENBROCK:
+        if (!c->calc_params || c->calc_params_len != 3) return -5;
+        break;
+    case SO_CALC_SKEWED_GAUSSIAN_2D:
+        if (!c->calc_params || c->calc_params_len != 1 || c->num_params != 2) return -5;
+        break;
+    default: return -6;
+    }
+    return 0;
+}
+
+int so_create(const so_config* cfg, so_sampler** out)
+{
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!out) return -1;
+    so_sampler* s = (so_sampler*)calloc(1, sizeof(*s));
+    if (!s) return -7;
+    s->cfg = *cfg;
+    size_t es = elem_size(cfg->dtype);
+    size_t W = (size_t)cfg->num_walkers, D = (size_t)cfg->num_params;
+    s->params = NULL;
+    if (cfg->calc_params_len > 0) {
+        s->params = malloc(es * (size_t)cfg->calc_params_len);
+        if (!s->params) { free(s); return -7; }
+        memcpy(s->params, cfg->calc_params, es * (size_t)cfg->calc_params_len);
+    }
+    s->cfg.calc_params = s->params;
+    s->pos = calloc(W * D, es);
+    s->logp = calloc(W, es);
+    s->n_accept = (uint32_t*)calloc(W, sizeof(uint32_t));
+    if (!s->pos || !s->logp || !s->n_accept) { so_destroy(s); return -7; }
+    so_pcg64_seed(&s->eng0, cfg->seed, cfg->stream);
+    *out = s;
+    return 0;
+}
+
+void so_destroy(so_sampler* s)
+{
+    if (!s) return;
+    free(s->params);
+    free(s->pos);
+    free(s->logp);
+    free(s->n_accept);
+    free(s);
+}
+
+/* EnsembleSampler::setInitialWalkerPos (EnsembleSampler.h:220-230): copies positions and aux
+ * values; the reference additionally counts the placement as one accepted step per walker
+ * (Walker.h:76,168) -- that offset is applied by callers, n_accept here counts proposals only. */
+int so_set_state(so_sampler* s, const void* positions, const void* logp)
+{
+    if (!s || !positions || !logp) return -1;
+    size_t es = elem_size(s->cfg.dtype);
+    size_t W = (size_t)s->cfg.num_walkers, D = (size_t)s->cfg.num_params;
+    memcpy(s->pos, positions, W * D * es);
+    memcpy(s->logp, logp, W * es);
+    memset(s->n_accept, 0, W * sizeof(uint32_t));
+    s->half_steps = 0;
+    s->near_ties = 0;
+    s->redraws = 0;
+    return 0;
+}
+
+int so_run(so_sampler* s, int64_t n_saved, int32_t interval, void* chain_out,
+           uint32_t* accepted_per_step, int32_t mode, int32_t threads)
+{
+    if (!s || n_saved < 0 || interval < 1) return -1;
+    if (mode != SO_MODE_SEQUENTIAL && mode != SO_MODE_COUNTER) return -2;
+    if (threads < 1) threads = 1;
+    if (threads > 1 && mode != SO_MODE_COUNTER) return -3;
+    if (s->cfg.dtype == SO_F64)
+        return run_f64(s, n_saved, interval, (double*)chain_out, accepted_per_step, mode, threads);
+    return run_f32(s, n_saved, interval, (float*)chain_out, accepted_per_step, mode, threads);
+}
+
+int so_get_state(so_sampler* s, void* positions, void* logp, uint32_t* n_accept)
+{
+    if (!s) return -1;
+    size_t es = elem_size(s->cfg.dtype);
+    size_t W = (size_t)s->cfg.num_walkers, D = (size_t)s->cfg.num_params;
+    if (positions) memcpy(positions, s->pos, W * D * es);
+    if (logp) memcpy(logp, s->logp, W * es);
+    if (n_accept) memcpy(n_accept, s->n_accept, W * sizeof(uint32_t));
+    return 0;
+}
+
+uint64_t so_half_steps_done(const so_sampler* s) { return s ? s->half_steps : 0; }
+uint64_t so_near_ties(const so_sampler* s) { return s ? s->near_ties : 0; }
+uint64_t so_redraws(const so_sampler* s) { return s ? s->redraws : 0; }
+
+int so_calc_logp(const so_config* cfg, const void* x, void* out)
+{
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!x || !out) return -1;
+    if (cfg->dtype == SO_F64)
+        *(double*)out = calc_logp_f64(cfg->calc_id, cfg->num_params, (const double*)cfg->calc_params,
+                                      (const double*)x);
+    else
+        *(float*)out = calc_logp_f32(cfg->calc_id, cfg->num_params, (const float*)cfg->calc_params,
+                                     (const float*)x);
+    return 0;
+}

@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REFERENCE itself.
+
+Run in the build container only (needs /root/reference; builds oracle/_ref/libmcmcpp_ref.so through
+oracle/Makefile).  Every fixture is data: inputs (initial positions / log-probabilities, calculator
+parameters, seed) and the reference's outputs (accepted-proposal count after every runMCMC(1) call,
+chain steps).  Large cases keep SHA-256 digests of the chain steps instead of the steps themselves.
+
+    python tests/golden/make_golden.py            # all fixtures
+    python tests/golden/make_golden.py iso64x4    # one
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import pyoracle as po  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ar1_precision(D, rho, t):
+    p = np.zeros((D, D), dtype=t)
+    rho = t(rho)
+    d = t(1) - rho * rho
+    for i in range(D):
+        edge = i == 0 or i == D - 1
+        p[i, i] = (t(1) if edge else (t(1) + rho * rho)) / d
+        if i + 1 < D:
+            p[i, i + 1] = -rho / d
+            p[i + 1, i] = -rho / d
+    return p
+
+
+CASES = {
+    # name: W, D, calc, params-maker, dtype, steps, slicing, chain steps kept in full
+    "iso64x4": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=1000, keep=[1, 2, 10, 1000]),
+    "iso100x7": dict(W=100, D=7, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=500, keep=[1, 2, 10, 500]),
+    "iso64x4_f32": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F32, steps=1000, keep=[1, 2, 10, 1000]),
+    "dense96x16": dict(W=96, D=16, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=300, keep=[1, 2, 10, 300],
+                       rho=0.5),
+    "dense80x5_f32": dict(W=80, D=5, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F32, steps=300, keep=[1, 2, 10, 300],
+                          rho=0.3),
+    "rosen80x8": dict(W=80, D=8, calc=po.CALC_ROSENBROCK, dtype=po.F64, steps=300, keep=[1, 2, 10, 300],
+                      params=[1.0, 100.0, 0.05]),
+    "rosen200x33": dict(W=200, D=33, calc=po.CALC_ROSENBROCK, dtype=po.F64, steps=100, keep=[1, 100],
+                        params=[1.0, 100.0, 0.05]),
+    "iso600x130": dict(W=600, D=130, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=40, keep=[],
+                       digest=[1, 2, 40], sample_rows=[0, 299, 300, 599]),
+    # the reference's own test set-up (test/sequential/SkewedGaussian/StretchMove/src/main.cpp:22-41),
+    # shortened to 200 stored steps of slicing 30; Calculator = the reference's SkewedGaussianTwoDim
+    "skewed320x2": dict(W=320, D=2, calc=po.CALC_SKEWED_GAUSSIAN_2D, dtype=po.F64, steps=200, slicing=30,
+                        keep=[1, 2, 200], params=[0.13], skewed_init=True),
+    # BASELINE config 2 (16 384 x 32 correlated Gaussian), 20 steps, digests only
+    "c2_16384x32": dict(W=16384, D=32, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=20, keep=[], rho=0.5,
+                        digest=[1, 2, 20], sample_rows=[0, 1, 8191, 8192, 16383]),
+    # BASELINE config 3 shape (Rosenbrock, D = 32) at a reduced walker count, digests only
+    "c3_4096x32": dict(W=4096, D=32, calc=po.CALC_ROSENBROCK, dtype=po.F64, steps=20, keep=[],
+                       params=[1.0, 100.0, 0.05], digest=[1, 2, 20], sample_rows=[0, 2047, 2048, 4095]),
+}
+
+
+def make(name, c):
+    W, D, dtype = c["W"], c["D"], c["dtype"]
+    t = po.np_dtype(dtype)
+    if "rho" in c:
+        params = ar1_precision(D, c["rho"], t).ravel()
+    elif "params" in c:
+        params = np.asarray(c["params"], dtype=t)
+    else:
+        params = None
+    orc = po.Oracle(W, D, c["calc"], params, seed=0, dtype=dtype)
+    if c.get("skewed_init"):
+        pos, logp = po.reference_skewed_initial_values(W, 0.13, 53)
+    else:
+        pos = po.init_positions(dtype, W, D, salt=0)
+        logp = orc.logp(pos)
+    slicing = c.get("slicing", 1)
+    steps = c["steps"]
+    ref = po.reference_run(W, D, c["calc"], params, 0, pos, logp, steps, 1, slicing=slicing, dtype=dtype)
+    assert ref["stored"] == steps + 1 and not ref["chain_full"]
+    acc_cum = ref["accepted"].astype(np.int64)
+    # reference totals count the initial placement as one accepted step per walker (Walker.h:76,168)
+    acc_per_call = np.diff(np.concatenate([[W], acc_cum])).astype(np.uint32)
+    out = dict(W=np.int32(W), D=np.int32(D), calc=np.int32(c["calc"]), dtype=np.int32(dtype), seed=np.int64(0),
+               slicing=np.int32(slicing), steps=np.int32(steps),
+               params=(np.zeros(0, dtype=t) if params is None else params),
+               accepted_per_call=acc_per_call, accepted_total=np.uint64(acc_cum[-1]),
+               total_steps=np.uint64(ref["total"][-1]))
+    big = bool(c.get("digest"))
+    if not big:
+        out["init_pos"] = pos
+        out["init_logp"] = logp
+    else:
+        out["init_pos_sha256"] = np.array(sha(pos))
+        out["init_logp_sha256"] = np.array(sha(logp))
+    chain = ref["chain"]
+    assert np.array_equal(chain[0], pos)
+    for k in c["keep"]:
+        out["chain_step_%d" % k] = chain[k]
+    for k in c.get("digest", []):
+        out["chain_sha256_step_%d" % k] = np.array(sha(chain[k]))
+        rows = c.get("sample_rows", [])
+        out["chain_rows_step_%d" % k] = chain[k][rows]
+    if c.get("sample_rows"):
+        out["sample_rows"] = np.asarray(c["sample_rows"], dtype=np.int32)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    return dict(name=name, W=W, D=D, steps=steps, slicing=slicing, accepted_total=int(acc_cum[-1]),
+                total_steps=int(ref["total"][-1]), bytes=os.path.getsize(path))
+
+
+def make_reference_test_run():
+    """The reference's SkewedGaussian/StretchMove test end to end (320 x 2, slicing 30, 40 019 stored
+    steps): its printed acceptance line is 'Acceptance Fraction: 274778560/384182720 | 0.715229'."""
+    W, D = 320, 2
+    pos, logp = po.reference_skewed_initial_values(W, 0.13, 53)
+    ref = po.reference_run(W, D, po.CALC_SKEWED_GAUSSIAN_2D, np.array([0.13]), 0, pos, logp, 1, 40019, slicing=30,
+                           want_chain=False)
+    out = dict(W=W, D=D, slicing=30, stored_steps=40019, eps=0.13, accepted_total=int(ref["accepted"][-1]),
+               total_steps=int(ref["total"][-1]), seconds_reference=ref["seconds"],
+               note="reference built with g++ -O2 -ffp-contract=off (oracle/Makefile); a build that lets the "
+                    "compiler contract a*b+c into FMA (e.g. -O3 -march=native) takes different accept decisions")
+    with open(os.path.join(HERE, "reference_skewed_test.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    return out
+
+
+def main():
+    want = sys.argv[1:]
+    if not po.reference_available():
+        sys.exit("oracle/_ref/libmcmcpp_ref.so is not available (no /root/reference here)")
+    summary = []
+    for name, c in CASES.items():
+        if want and name not in want:
+            continue
+        summary.append(make(name, c))
+        print(summary[-1], flush=True)
+    if not want or "reference_skewed_test" in want:
+        print(make_reference_test_run(), flush=True)
+    if not want:
+        with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
