@@ -1,0 +1,152 @@
+/*
+ * mcmcpp_hip.h -- C ABI of libmcmcpp_hip.so, the MI355X (gfx950) implementation of the reference's
+ * stretch-move ensemble step.
+ *
+ * The reference (jmatta1/MCMCpp) is a header-only C++ template library and has no FFI of its own; the
+ * boundary below is what its sampler facade would bind for this path.  Each entry point names the
+ * reference interface it stands in for (paths relative to /root/reference).  The header-only host
+ * facade in include/MCMCpp/ (same class names and template parameters as the reference) is the only
+ * intended caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C types only; every function returns MCMCPP_HIP_OK (0) or a positive error code
+ * and never throws; pointers are caller-owned HOST memory unless the name says `device`; a handle is
+ * used from one host thread at a time (the facade keeps the reference's sampler mutex,
+ * ParallelEnsembleSampler.h:184-210); the handle owns all device buffers, streams and graphs.
+ *
+ * Data layout (same as the reference's setInitialWalkerPos arguments and Chain cells,
+ * EnsembleSampler.h:220-230, Chain/ChainBlock.h:125-131):
+ *   positions[w*D + p]   walker-major, parameter-contiguous; walkers [0, W/2) are the red half,
+ *                        [W/2, W) the black half (EnsembleSampler.h:211-215)
+ *   logp[w]              the walker's auxiliary value = log-posterior of its position
+ *   chain[s*W*D + w*D + p]  stored step s
+ */
+#ifndef MCMCPP_HIP_H
+#define MCMCPP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCMCPP_HIP_ABI_VERSION 1
+
+/* return codes */
+enum {
+    MCMCPP_HIP_OK = 0,
+    MCMCPP_HIP_E_ARG = 1,         /* bad argument (the reference asserts: EnsembleSampler.h:207-208,327,335) */
+    MCMCPP_HIP_E_HIP = 2,         /* a HIP runtime call failed; see mcmcpp_hip_last_error */
+    MCMCPP_HIP_E_NO_DEVICE = 3,   /* no gfx950 device / device ordinal out of range */
+    MCMCPP_HIP_E_UNSUPPORTED = 4, /* configuration outside what the kernels were built for */
+    MCMCPP_HIP_E_STATE = 5,       /* run/get before set_state */
+    MCMCPP_HIP_E_NOMEM = 6
+};
+
+/* ParamType of the reference templates */
+enum { MCMCPP_HIP_F64 = 0, MCMCPP_HIP_F32 = 1 };
+
+/* device Calculators (reference concept: ParamType calcLogPostProb(ParamType*),
+ * Utility/UserOjbectsTest.h:144-145); host twins live in include/MCMCpp/Device/Calculators.h */
+enum {
+    MCMCPP_HIP_CALC_ISO_GAUSSIAN = 0,      /* params: none                    */
+    MCMCPP_HIP_CALC_DENSE_GAUSSIAN = 1,    /* params: P[D*D] row-major        */
+    MCMCPP_HIP_CALC_ROSENBROCK = 2,        /* params: a, b, c                 */
+    MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D = 3 /* params: epsilon; requires D == 2 */
+};
+
+typedef struct mcmcpp_hip_sampler mcmcpp_hip_sampler;
+
+/* Stands in for the constructor arguments of EnsembleSampler (EnsembleSampler.h:66-67,199-218),
+ * ParallelEnsembleSampler (ParallelEnsembleSampler.h:119-120) and StretchMove (Movers/StretchMove.h:62-66). */
+typedef struct mcmcpp_hip_config {
+    uint32_t struct_size;    /* sizeof(mcmcpp_hip_config) */
+    int32_t dtype;           /* MCMCPP_HIP_F64 / MCMCPP_HIP_F32 */
+    int32_t num_walkers;     /* W: even and > 2*D */
+    int32_t num_params;      /* D: 1..1024 */
+    int32_t calc_id;         /* MCMCPP_HIP_CALC_* */
+    int32_t calc_params_len; /* number of dtype elements behind calc_params */
+    const void* calc_params; /* host pointer, copied */
+    uint64_t seed;           /* randSeed, sign-extended to 64 bit (MultiSampler.h:54) */
+    uint64_t stream;         /* pcg stream; EnsembleSampler uses 0 (EnsembleSampler.h:217) */
+    int32_t device;          /* HIP device ordinal, -1 = the current device */
+    /* Walkers of each half updated by this handle: [shard_begin, shard_begin + shard_count) of W/2.
+     * shard_count == 0 means the whole half.  A sharded handle still holds the full ensemble (the
+     * complementary half must be readable); the caller exchanges the updated rows between handles
+     * after every half-step (see mcmcpp_hip_half_step_async). */
+    int32_t shard_begin;
+    int32_t shard_count;
+    int32_t graph_steps;     /* ensemble steps per hipGraph replay; 0 = library default, -1 = no graphs */
+    void* device_positions;  /* optional caller-owned DEVICE buffer of W*D elements used in place of an
+                                internal one (e.g. memory registered with a collective library) */
+    void* hip_stream;        /* optional hipStream_t to launch on; NULL = a stream owned by the handle */
+} mcmcpp_hip_config;
+
+/* EnsembleSampler::EnsembleSampler / ~EnsembleSampler */
+int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out);
+void mcmcpp_hip_destroy(mcmcpp_hip_sampler* h);
+
+/* message of the last failure on this handle (h == NULL: last failure of mcmcpp_hip_create on this thread) */
+const char* mcmcpp_hip_last_error(const mcmcpp_hip_sampler* h);
+
+/* EnsembleSampler::setInitialWalkerPos (EnsembleSampler.h:220-230): uploads positions[W*D] and
+ * auxValues[W], zeroes the per-walker counters and rewinds the random stream to its first draw. */
+int mcmcpp_hip_set_state(mcmcpp_hip_sampler* h, const void* positions, const void* logp);
+
+/* EnsembleSampler::runMCMC (EnsembleSampler.h:284-310) with the slicing mode of setSlicingMode folded in:
+ * executes n_saved*interval ensemble steps (red half-step then black half-step each,
+ * EnsembleSampler.h:341-354); the last step of every `interval` is a stored step.
+ *   chain_out          n_saved*W*D elements receiving the stored steps, or NULL to store nothing
+ *   accepted_per_step  n_saved*interval counters (accepted proposals of each executed ensemble step), or NULL
+ * Synchronous: returns when the results are in host memory. */
+int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out,
+                   uint32_t* accepted_per_step);
+
+/* Current walker state (what Walker::getCurrState / getCurrAuxData / getAcceptedProposals expose,
+ * Walker/Walker.h:111-122).  n_accept[w] counts accepted proposals since set_state or reset_counters;
+ * the reference additionally counts the initial placement (Walker.h:76,168) -- the facade adds it.
+ * Any pointer may be NULL. */
+int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept);
+
+/* EnsembleSampler::reset (EnsembleSampler.h:312-322): zero the counters, keep positions and stream. */
+int mcmcpp_hip_reset_counters(mcmcpp_hip_sampler* h);
+
+/* getAcceptedSteps / getTotalSteps material (EnsembleSampler.h:260-282), plus two parity diagnostics:
+ *   accepted        sum of n_accept over the walkers this handle updates
+ *   ensemble_steps  ensemble steps executed since set_state / reset_counters
+ *   near_ties       accept decisions whose margin was within a few ulp (could flip under another libm log)
+ *   redraws         pcg bounded_rand rejections met (only possible when W/2 is not a power of two; the
+ *                   reference would have consumed one more draw there, so trajectories part)
+ * Any pointer may be NULL. */
+int mcmcpp_hip_get_counters(mcmcpp_hip_sampler* h, uint64_t* accepted, uint64_t* ensemble_steps,
+                            uint64_t* near_ties, uint64_t* redraws);
+
+/* Calculator::calcLogPostProb evaluated by the device functor for `count` D-vectors (host in, host out). */
+int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t count, void* logp_out);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+
+/* GPU time of the last mcmcpp_hip_run between HIP events recorded on the launch stream around the
+ * half-step launches (excludes uploads / downloads), and the number of half-step launches it covers. */
+int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* half_step_launches);
+
+/* ---- multi-GPU single ensemble (one handle per GPU) -------------------------------- */
+
+/* Enqueue ONE half-step (color 0 = red, 1 = black) for this handle's shard on its stream and return
+ * without waiting.  The caller then exchanges the updated rows (device_positions + offset, see
+ * mcmcpp_hip_shard_span) with the other handles -- e.g. an in-place RCCL all-gather on the same
+ * stream -- before enqueueing the next half-step.  save_slot >= 0 also writes the shard's rows of
+ * that stored step into the device chain buffer given to mcmcpp_hip_bind_device_chain. */
+int mcmcpp_hip_half_step_async(mcmcpp_hip_sampler* h, int32_t color, int64_t save_slot);
+int mcmcpp_hip_bind_device_chain(mcmcpp_hip_sampler* h, void* device_chain, int64_t slots);
+/* device pointer of the ensemble positions (W*D elements) and the element span [offset, offset+count)
+ * this handle rewrites during a half-step of `color` */
+void* mcmcpp_hip_device_positions(mcmcpp_hip_sampler* h);
+int mcmcpp_hip_shard_span(mcmcpp_hip_sampler* h, int32_t color, int64_t* offset_elems, int64_t* count_elems);
+int mcmcpp_hip_synchronize(mcmcpp_hip_sampler* h);
+
+int mcmcpp_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCMCPP_HIP_H */

@@ -1,0 +1,175 @@
+"""ctypes binding of include/mcmcpp_hip.h.  There is no CPU fallback: if libmcmcpp_hip.so cannot be
+loaded, or a call fails, an exception carrying the library's own error message is raised."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+F64, F32 = 0, 1
+CALC_ISO_GAUSSIAN, CALC_DENSE_GAUSSIAN, CALC_ROSENBROCK, CALC_SKEWED_GAUSSIAN_2D = 0, 1, 2, 3
+OK = 0
+
+# every symbol include/mcmcpp_hip.h declares
+EXPORTS = [
+    "mcmcpp_hip_abi_version", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
+    "mcmcpp_hip_set_state", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
+    "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing",
+    "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
+    "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("dtype", C.c_int32), ("num_walkers", C.c_int32),
+                ("num_params", C.c_int32), ("calc_id", C.c_int32), ("calc_params_len", C.c_int32),
+                ("calc_params", C.c_void_p), ("seed", C.c_uint64), ("stream", C.c_uint64), ("device", C.c_int32),
+                ("shard_begin", C.c_int32), ("shard_count", C.c_int32), ("graph_steps", C.c_int32),
+                ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmcmcpp_hip.so")
+
+
+def build_library(force=False):
+    """Compile every HIP source for gfx950 into mcmcpp_amd/libmcmcpp_hip.so (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    if force:
+        subprocess.check_call(args + ["clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return library_path()
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(there is no CPU fallback)" % path)
+        L = C.CDLL(path)
+        vp, i32, i64, u64p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_uint64)
+        L.mcmcpp_hip_abi_version.restype = C.c_int
+        L.mcmcpp_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.mcmcpp_hip_destroy.argtypes = [vp]
+        L.mcmcpp_hip_destroy.restype = None
+        L.mcmcpp_hip_last_error.argtypes = [vp]
+        L.mcmcpp_hip_last_error.restype = C.c_char_p
+        L.mcmcpp_hip_set_state.argtypes = [vp, vp, vp]
+        L.mcmcpp_hip_run.argtypes = [vp, i64, i32, vp, vp]
+        L.mcmcpp_hip_get_state.argtypes = [vp, vp, vp, vp]
+        L.mcmcpp_hip_reset_counters.argtypes = [vp]
+        L.mcmcpp_hip_get_counters.argtypes = [vp, u64p, u64p, u64p, u64p]
+        L.mcmcpp_hip_calc_logp.argtypes = [vp, vp, i64, vp]
+        L.mcmcpp_hip_last_run_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+        L.mcmcpp_hip_half_step_async.argtypes = [vp, i32, i64]
+        L.mcmcpp_hip_bind_device_chain.argtypes = [vp, vp, i64]
+        L.mcmcpp_hip_device_positions.argtypes = [vp]
+        L.mcmcpp_hip_device_positions.restype = vp
+        L.mcmcpp_hip_shard_span.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
+        L.mcmcpp_hip_synchronize.argtypes = [vp]
+        _lib = L
+    return _lib
+
+
+def np_dtype(dtype):
+    return np.float64 if dtype == F64 else np.float32
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class HipError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "mcmcpp_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class HipSampler:
+    """Thin owner of one mcmcpp_hip_sampler handle (one GPU)."""
+
+    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, device=-1, shard_begin=0,
+                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None):
+        self.W, self.D, self.dtype = W, D, dtype
+        self.np_t = np_dtype(dtype)
+        self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
+        self.cfg = Config(C.sizeof(Config), dtype, W, D, calc_id, 0 if self.params is None else self.params.size,
+                          _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
+                          shard_count, graph_steps, device_positions, hip_stream)
+        self.h = C.c_void_p()
+        rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != OK:
+            raise HipError(rc, lib().mcmcpp_hip_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mcmcpp_hip_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != OK:
+            raise HipError(rc, lib().mcmcpp_hip_last_error(self.h).decode())
+
+    def set_state(self, pos, logp):
+        pos = np.ascontiguousarray(pos, dtype=self.np_t)
+        logp = np.ascontiguousarray(logp, dtype=self.np_t)
+        assert pos.size == self.W * self.D and logp.size == self.W
+        self._check(lib().mcmcpp_hip_set_state(self.h, _ptr(pos), _ptr(logp)))
+
+    def run(self, n_saved, interval=1, save_chain=True, want_accepted=True):
+        chain = np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None
+        acc = np.zeros(n_saved * interval, dtype=np.uint32) if want_accepted else None
+        self._check(lib().mcmcpp_hip_run(self.h, n_saved, interval, _ptr(chain), _ptr(acc)))
+        return chain, acc
+
+    def get_state(self):
+        pos = np.empty((self.W, self.D), dtype=self.np_t)
+        logp = np.empty(self.W, dtype=self.np_t)
+        nacc = np.empty(self.W, dtype=np.uint32)
+        self._check(lib().mcmcpp_hip_get_state(self.h, _ptr(pos), _ptr(logp), _ptr(nacc)))
+        return pos, logp, nacc
+
+    def reset_counters(self):
+        self._check(lib().mcmcpp_hip_reset_counters(self.h))
+
+    def counters(self):
+        v = [C.c_uint64(0) for _ in range(4)]
+        self._check(lib().mcmcpp_hip_get_counters(self.h, *[C.byref(x) for x in v]))
+        return dict(accepted=v[0].value, ensemble_steps=v[1].value, near_ties=v[2].value, redraws=v[3].value)
+
+    def calc_logp(self, pos):
+        pos = np.ascontiguousarray(pos, dtype=self.np_t).reshape(-1, self.D)
+        out = np.empty(pos.shape[0], dtype=self.np_t)
+        self._check(lib().mcmcpp_hip_calc_logp(self.h, _ptr(pos), pos.shape[0], _ptr(out)))
+        return out
+
+    def last_run_timing(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        self._check(lib().mcmcpp_hip_last_run_timing(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def half_step_async(self, color, save_slot=-1):
+        self._check(lib().mcmcpp_hip_half_step_async(self.h, color, save_slot))
+
+    def bind_device_chain(self, ptr, slots):
+        self._check(lib().mcmcpp_hip_bind_device_chain(self.h, ptr, slots))
+
+    def device_positions(self):
+        return lib().mcmcpp_hip_device_positions(self.h)
+
+    def shard_span(self, color):
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        self._check(lib().mcmcpp_hip_shard_span(self.h, color, C.byref(off), C.byref(cnt)))
+        return off.value, cnt.value
+
+    def synchronize(self):
+        self._check(lib().mcmcpp_hip_synchronize(self.h))

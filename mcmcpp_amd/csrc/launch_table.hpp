@@ -1,0 +1,36 @@
+// launch_table.hpp -- host-side dispatch tables over the kernel instantiations.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "stretch_kernel.hpp"
+
+namespace mcmcpp
+{
+
+// index of EPL among {base, 2*base, 4*base, 8*base}; base = 16 bytes / sizeof(T)
+constexpr int kMaxEplShift = 4;
+constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
+
+template <class T>
+struct LaunchTable
+{
+    typedef void (*HalfStepFn)(const HalfStepArgs<T>&, unsigned grid, hipStream_t);
+    typedef void (*CalcFn)(const T* pos, T* out, const T* params, long long count, int dims, int vec_ok, unsigned grid,
+                           hipStream_t);
+    // [log2(LPW)][log2(EPL/base)]; nullptr where not built
+    HalfStepFn half_step[kLpwLevels][kMaxEplShift];
+    CalcFn calc[kLpwLevels][kMaxEplShift];
+};
+
+// one definition per (element type, calculator), each in its own translation unit
+const LaunchTable<double>* launch_table_f64_iso();
+const LaunchTable<double>* launch_table_f64_dense();
+const LaunchTable<double>* launch_table_f64_rosenbrock();
+const LaunchTable<double>* launch_table_f64_skewed();
+const LaunchTable<float>* launch_table_f32_iso();
+const LaunchTable<float>* launch_table_f32_dense();
+const LaunchTable<float>* launch_table_f32_rosenbrock();
+const LaunchTable<float>* launch_table_f32_skewed();
+
+}  // namespace mcmcpp

@@ -1,0 +1,786 @@
+// mcmcpp_hip.hip -- host side of libmcmcpp_hip.so: the C ABI of include/mcmcpp_hip.h on top of the
+// gfx950 kernels in stretch_kernel.hpp.
+//
+// Reference roles replaced (paths relative to /root/reference):
+//   EnsembleSampler ctor / setInitialWalkerPos / runMCMC / reset / counters  MCMCpp/EnsembleSampler.h:199-360
+//   ParallelEnsembleSampler's thread pool + red/black controller             MCMCpp/Threading/*.h
+//     -> one kernel launch per half-step on one HIP stream, replayed from a hipGraph; the stream and
+//        step counters travel in device memory (StepCtl) so a replay needs no host-side updates
+//   Walker[] (heap row per walker)  MCMCpp/Walker/Walker.h:142-149 -> pos[W][D], logp[W], n_accept[W] in HBM
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mcmcpp_hip.h"
+#include "launch_table.hpp"
+
+using namespace mcmcpp;
+
+namespace
+{
+thread_local std::string g_create_error;
+
+int pow2_at_least(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+Affine128 compose(const Affine128& g, const Affine128& f)  // g after f
+{
+    Affine128 r;
+    r.mult = mul128(g.mult, f.mult);
+    r.plus = add128(mul128(g.mult, f.plus), g.plus);
+    return r;
+}
+
+long env_long(const char* name, long fallback)
+{
+    const char* v = std::getenv(name);
+    return (v && *v) ? std::strtol(v, nullptr, 10) : fallback;
+}
+
+template <class T>
+const LaunchTable<T>* table_for(int calc_id);
+template <>
+const LaunchTable<double>* table_for<double>(int calc_id)
+{
+    switch (calc_id)
+    {
+    case MCMCPP_HIP_CALC_ISO_GAUSSIAN: return launch_table_f64_iso();
+    case MCMCPP_HIP_CALC_DENSE_GAUSSIAN: return launch_table_f64_dense();
+    case MCMCPP_HIP_CALC_ROSENBROCK: return launch_table_f64_rosenbrock();
+    case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D: return launch_table_f64_skewed();
+    default: return nullptr;
+    }
+}
+template <>
+const LaunchTable<float>* table_for<float>(int calc_id)
+{
+    switch (calc_id)
+    {
+    case MCMCPP_HIP_CALC_ISO_GAUSSIAN: return launch_table_f32_iso();
+    case MCMCPP_HIP_CALC_DENSE_GAUSSIAN: return launch_table_f32_dense();
+    case MCMCPP_HIP_CALC_ROSENBROCK: return launch_table_f32_rosenbrock();
+    case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D: return launch_table_f32_skewed();
+    default: return nullptr;
+    }
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+struct mcmcpp_hip_sampler
+{
+    std::string error;
+    virtual ~mcmcpp_hip_sampler() {}
+    virtual int set_state(const void* pos, const void* logp) = 0;
+    virtual int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) = 0;
+    virtual int get_state(void* pos, void* logp, uint32_t* n_accept) = 0;
+    virtual int reset_counters() = 0;
+    virtual int get_counters(uint64_t* accepted, uint64_t* steps, uint64_t* ties, uint64_t* redraws) = 0;
+    virtual int calc_logp(const void* pos, int64_t count, void* out) = 0;
+    virtual int last_run_timing(double* ms, int64_t* launches) = 0;
+    virtual int half_step_async(int32_t color, int64_t save_slot) = 0;
+    virtual int bind_device_chain(void* chain, int64_t slots) = 0;
+    virtual void* device_positions() = 0;
+    virtual int shard_span(int32_t color, int64_t* off, int64_t* cnt) = 0;
+    virtual int synchronize() = 0;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(expr)                                                                                       \
+    do                                                                                                      \
+    {                                                                                                       \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(MCMCPP_HIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+namespace
+{
+template <class T>
+class Sampler final : public mcmcpp_hip_sampler
+{
+public:
+    Sampler() {}
+    ~Sampler() override { release(); }
+
+    int init(const mcmcpp_hip_config& c)
+    {
+        cfg = c;
+        W = c.num_walkers;
+        D = c.num_params;
+        n = W / 2;
+        table = table_for<T>(c.calc_id);
+        if (!table) return fail(MCMCPP_HIP_E_ARG, "unknown calc_id %d", c.calc_id);
+
+        // lane mapping: LPW lanes x EPL elements cover the walker's D-vector padded to a power of two
+        const int base = Vec16<T>::N;
+        const int n2 = pow2_at_least(D > base ? D : base);
+        lpw = n2 / base < 64 ? n2 / base : 64;
+        epl = n2 / lpw;
+        const int lpw_log = ilog2(lpw), epl_shift = ilog2(epl / base);
+        if (epl_shift >= kMaxEplShift || !table->half_step[lpw_log][epl_shift])
+            return fail(MCMCPP_HIP_E_UNSUPPORTED, "no kernel for D=%d with this calculator (LPW=%d EPL=%d)", D, lpw, epl);
+        half_fn = table->half_step[lpw_log][epl_shift];
+        calc_fn = table->calc[lpw_log][epl_shift];
+        vec_ok = (D % base == 0) ? 1 : 0;
+
+        shard_begin = c.shard_begin;
+        shard_count = c.shard_count > 0 ? c.shard_count : n;
+        if (shard_begin < 0 || shard_begin + shard_count > n) return fail(MCMCPP_HIP_E_ARG, "shard out of range");
+
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(MCMCPP_HIP_E_NO_DEVICE, "no HIP device visible to this process");
+        if (c.device >= ndev) return fail(MCMCPP_HIP_E_NO_DEVICE, "device %d out of range (%d visible)", c.device, ndev);
+        if (c.device >= 0)
+            device = c.device;
+        else
+            HIP_TRY(hipGetDevice(&device));
+        HIP_TRY(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(MCMCPP_HIP_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
+                        prop.gcnArchName);
+        num_cus = prop.multiProcessorCount;
+
+        // walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then amortise phase A
+        const int wpp = 64 / lpw;
+        long forced = env_long("MCMCPP_HIP_PASSES", 0);
+        if (forced > 0)
+            passes = (int)forced;
+        else
+        {
+            const long target_waves = (long)num_cus * 4 * env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
+            passes = 1;
+            while (passes * 2 <= lpw && (long)shard_count / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
+        }
+        if (passes < 1) passes = 1;
+        if (passes > lpw) passes = lpw;
+
+        if (c.hip_stream)
+        {
+            stream = (hipStream_t)c.hip_stream;
+            own_stream = false;
+        }
+        else
+        {
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            own_stream = true;
+        }
+        HIP_TRY(hipEventCreate(&ev_start));
+        HIP_TRY(hipEventCreate(&ev_stop));
+
+        if (c.device_positions)
+        {
+            if (((uintptr_t)c.device_positions & 15u) != 0) return fail(MCMCPP_HIP_E_ARG, "device_positions must be 16-byte aligned");
+            d_pos = (T*)c.device_positions;
+            own_pos = false;
+        }
+        else
+        {
+            HIP_TRY(hipMalloc(&d_pos, sizeof(T) * (size_t)W * D));
+            own_pos = true;
+        }
+        HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
+        HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
+        HIP_TRY(hipMalloc(&d_ctl, sizeof(StepCtl) * 2));
+        HIP_TRY(hipMalloc(&d_run, sizeof(RunInfo)));
+        HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
+        HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
+        HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
+        HIP_TRY(hipMemset(d_run, 0, sizeof(RunInfo)));
+        HIP_TRY(hipMemset(d_ctl, 0, sizeof(StepCtl) * 2));
+        HIP_TRY(hipHostMalloc(&h_pinned, 256, hipHostMallocDefault));
+
+        // calculator parameters (the dense Gaussian's matrix goes over transposed: see DenseGaussianFn)
+        if (c.calc_params_len > 0)
+        {
+            std::vector<T> prm((const T*)c.calc_params, (const T*)c.calc_params + c.calc_params_len);
+            if (c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN)
+            {
+                const T* p = (const T*)c.calc_params;
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) prm[(size_t)j * D + i] = p[(size_t)i * D + j];
+            }
+            HIP_TRY(hipMalloc(&d_params, sizeof(T) * prm.size()));
+            HIP_TRY(hipMemcpy(d_params, prm.data(), sizeof(T) * prm.size(), hipMemcpyHostToDevice));
+        }
+
+        // pcg64 stream (MultiSampler.h:54) and its jump tables
+        pcg_seed(c.seed, c.stream, &state0, &inc);
+        {
+            std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256);
+            const Affine128 step3 = pcg_jump(inc, 3);
+            lo[0].mult = make_u128(0, 1);
+            lo[0].plus = make_u128(0, 0);
+            for (int k = 1; k < 256; ++k) lo[k] = compose(step3, lo[k - 1]);
+            const Affine128 step768 = pcg_jump(inc, 768);
+            hi[0] = lo[0];
+            for (size_t m = 1; m < hi.size(); ++m) hi[m] = compose(step768, hi[m - 1]);
+            HIP_TRY(hipMalloc(&d_jump_lo, sizeof(Affine128) * lo.size()));
+            HIP_TRY(hipMalloc(&d_jump_hi, sizeof(Affine128) * hi.size()));
+            HIP_TRY(hipMemcpy(d_jump_lo, lo.data(), sizeof(Affine128) * lo.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
+        }
+        half_jump = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n);
+
+        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 32) : c.graph_steps;
+        chain_chunk_bytes = (size_t)env_long("MCMCPP_HIP_CHAIN_CHUNK_MB", 4096) << 20;
+        return MCMCPP_HIP_OK;
+    }
+
+    int set_state(const void* pos, const void* logp) override
+    {
+        if (!pos || !logp) return fail(MCMCPP_HIP_E_ARG, "set_state: null pointer");
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemcpyAsync(d_pos, pos, sizeof(T) * (size_t)W * D, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(d_logp, logp, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
+        HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(Diag), stream));
+        half_steps = 0;
+        steps_since_reset = 0;
+        int rc = write_ctl(0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        have_state = true;
+        return MCMCPP_HIP_OK;
+    }
+
+    int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) override
+    {
+        if (!have_state) return fail(MCMCPP_HIP_E_STATE, "run: set_state has not been called");
+        if (n_saved < 0 || interval < 1) return fail(MCMCPP_HIP_E_ARG, "run: n_saved >= 0 and interval >= 1 required");
+        if (shard_count != n) return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: a sharded handle is driven with half_step_async");
+        if (half_steps & 1) return fail(MCMCPP_HIP_E_STATE, "run: an ensemble step is half done (half_step_async)");
+        HIP_TRY(hipSetDevice(device));
+        const int64_t total = n_saved * (int64_t)interval;
+        last_ms = 0.0;
+        last_launches = 0;
+        if (total == 0) return MCMCPP_HIP_OK;
+
+        uint32_t* d_acc = nullptr;
+        if (accepted_per_step)
+        {
+            HIP_TRY(hipMalloc(&d_acc, sizeof(uint32_t) * (size_t)total));
+            HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
+        }
+        const size_t step_bytes = sizeof(T) * (size_t)W * D;
+        int64_t chunk_saved = n_saved;
+        T* d_chain = nullptr;
+        if (chain_out)
+        {
+            chunk_saved = (int64_t)(chain_chunk_bytes / step_bytes);
+            if (chunk_saved < 1) chunk_saved = 1;
+            if (chunk_saved > n_saved) chunk_saved = n_saved;
+            hipError_t e = hipMalloc(&d_chain, step_bytes * (size_t)chunk_saved);
+            if (e != hipSuccess)
+            {
+                if (d_acc) hipFree(d_acc);
+                return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of device chain", step_bytes * (size_t)chunk_saved);
+            }
+        }
+        int rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
+        int64_t saved_done = 0;
+        while (rc == MCMCPP_HIP_OK && saved_done < n_saved)
+        {
+            const int64_t now = (n_saved - saved_done < chunk_saved) ? n_saved - saved_done : chunk_saved;
+            RunInfo* ri = (RunInfo*)h_pinned;
+            ri->chain = d_chain;
+            ri->accepted_per_step = d_acc;
+            ri->interval = interval;
+            ri->chain_slot_base = -saved_done;
+            rc = hip_rc(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream), "RunInfo upload");
+            if (rc) break;
+            rc = hip_rc(hipStreamSynchronize(stream), "sync before launches");  // pinned block is reused below
+            if (rc) break;
+            rc = launch_steps(now * interval);
+            if (rc) break;
+            if (d_chain)
+                rc = hip_rc(hipMemcpyAsync((char*)chain_out + step_bytes * (size_t)saved_done, d_chain, step_bytes * (size_t)now,
+                                           hipMemcpyDeviceToHost, stream), "chain download");
+            if (rc) break;
+            rc = hip_rc(hipStreamSynchronize(stream), "sync after chunk");
+            saved_done += now;
+        }
+        {
+            // leave no pointer to the buffers freed below in the device-side RunInfo
+            const int rc2 = upload_idle_run_info();
+            if (rc == MCMCPP_HIP_OK) rc = rc2;
+        }
+        if (rc == MCMCPP_HIP_OK && d_acc)
+            rc = hip_rc(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost), "accepted download");
+        if (d_chain) hipFree(d_chain);
+        if (d_acc) hipFree(d_acc);
+        return rc;
+    }
+
+    int get_state(void* pos, void* logp, uint32_t* n_accept) override
+    {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (pos) HIP_TRY(hipMemcpy(pos, d_pos, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToHost));
+        if (logp) HIP_TRY(hipMemcpy(logp, d_logp, sizeof(T) * (size_t)W, hipMemcpyDeviceToHost));
+        if (n_accept) HIP_TRY(hipMemcpy(n_accept, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
+        return MCMCPP_HIP_OK;
+    }
+
+    int reset_counters() override
+    {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        steps_since_reset = 0;
+        return MCMCPP_HIP_OK;
+    }
+
+    int get_counters(uint64_t* accepted, uint64_t* steps, uint64_t* ties, uint64_t* redraws) override
+    {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (accepted)
+        {
+            std::vector<uint32_t> a((size_t)W);
+            HIP_TRY(hipMemcpy(a.data(), d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
+            uint64_t s = 0;
+            for (int c = 0; c < 2; ++c)
+                for (int i = 0; i < shard_count; ++i) s += a[(size_t)c * n + shard_begin + i];
+            *accepted = s;
+        }
+        if (steps) *steps = steps_since_reset;
+        if (ties || redraws)
+        {
+            Diag d;
+            HIP_TRY(hipMemcpy(&d, d_diag, sizeof(Diag), hipMemcpyDeviceToHost));
+            if (ties) *ties = d.near_ties;
+            if (redraws) *redraws = d.redraws;
+        }
+        return MCMCPP_HIP_OK;
+    }
+
+    int calc_logp(const void* pos, int64_t count, void* out) override
+    {
+        if (count < 0 || (count > 0 && (!pos || !out))) return fail(MCMCPP_HIP_E_ARG, "calc_logp: bad arguments");
+        if (count == 0) return MCMCPP_HIP_OK;
+        HIP_TRY(hipSetDevice(device));
+        T *dp = nullptr, *dout = nullptr;
+        HIP_TRY(hipMalloc(&dp, sizeof(T) * (size_t)count * D));
+        HIP_TRY(hipMalloc(&dout, sizeof(T) * (size_t)count));
+        HIP_TRY(hipMemcpyAsync(dp, pos, sizeof(T) * (size_t)count * D, hipMemcpyHostToDevice, stream));
+        const long long per_block = (long long)(64 / lpw) * kWavesPerBlock;
+        const unsigned grid = (unsigned)((count + per_block - 1) / per_block);
+        calc_fn(dp, dout, d_params, count, D, vec_ok, grid, stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, dout, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        hipFree(dp);
+        hipFree(dout);
+        return MCMCPP_HIP_OK;
+    }
+
+    int last_run_timing(double* ms, int64_t* launches) override
+    {
+        if (ms) *ms = last_ms;
+        if (launches) *launches = last_launches;
+        return MCMCPP_HIP_OK;
+    }
+
+    int half_step_async(int32_t color, int64_t save_slot) override
+    {
+        if (!have_state) return fail(MCMCPP_HIP_E_STATE, "half_step_async: set_state has not been called");
+        if (color != (int)(half_steps & 1)) return fail(MCMCPP_HIP_E_ARG, "half_step_async: colour %d out of order", color);
+        if (save_slot >= 0 && (!bound_chain || save_slot >= bound_slots))
+            return fail(MCMCPP_HIP_E_ARG, "half_step_async: save_slot outside the bound device chain");
+        HIP_TRY(hipSetDevice(device));
+        HalfStepArgs<T> a = make_args(color);
+        a.use_ctl_save = 0;
+        a.direct_save_slot = save_slot;
+        half_fn(a, grid_blocks(), stream);
+        HIP_TRY(hipGetLastError());
+        half_steps += 1;
+        if (color == 1) steps_since_reset += 1;
+        return MCMCPP_HIP_OK;
+    }
+
+    int bind_device_chain(void* chain, int64_t slots) override
+    {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        bound_chain = chain;
+        bound_slots = chain ? slots : 0;
+        return upload_idle_run_info();
+    }
+
+    void* device_positions() override { return d_pos; }
+
+    int shard_span(int32_t color, int64_t* off, int64_t* cnt) override
+    {
+        if (color != 0 && color != 1) return fail(MCMCPP_HIP_E_ARG, "shard_span: colour must be 0 or 1");
+        if (off) *off = ((int64_t)(color ? n : 0) + shard_begin) * D;
+        if (cnt) *cnt = (int64_t)shard_count * D;
+        return MCMCPP_HIP_OK;
+    }
+
+    int synchronize() override
+    {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MCMCPP_HIP_OK;
+    }
+
+private:
+    int hip_rc(hipError_t e, const char* what)
+    {
+        if (e == hipSuccess) return MCMCPP_HIP_OK;
+        return fail(MCMCPP_HIP_E_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    }
+
+    // RunInfo used outside run(): the chain bound for half_step_async (if any), no per-step counters
+    int upload_idle_run_info()
+    {
+        RunInfo ri;
+        ri.chain = bound_chain;
+        ri.accepted_per_step = nullptr;
+        ri.interval = 1;
+        ri.chain_slot_base = 0;
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(d_run, &ri, sizeof ri, hipMemcpyHostToDevice));
+        return MCMCPP_HIP_OK;
+    }
+
+    unsigned grid_blocks() const
+    {
+        const long per_wave = (long)(64 / lpw) * passes;
+        const long waves = (shard_count + per_wave - 1) / per_wave;
+        return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    }
+
+    HalfStepArgs<T> make_args(int color) const
+    {
+        HalfStepArgs<T> a;
+        std::memset(&a, 0, sizeof a);
+        a.pos = d_pos;
+        a.logp = d_logp;
+        a.n_accept = d_nacc;
+        a.ctl_in = d_ctl + color;
+        a.ctl_out = d_ctl + (1 - color);
+        a.run = d_run;
+        a.diag = d_diag;
+        a.jump_lo = d_jump_lo;
+        a.jump_hi = d_jump_hi;
+        a.calc_params = d_params;
+        a.half_jump = half_jump;
+        a.inc = inc;
+        a.redraw_threshold = (uint64_t)(0 - (uint64_t)n) % (uint64_t)n;
+        // GwDistribution<T,2,1> (MCMCpp/Utility/GwDistribution.h:45-55)
+        const T sqrt_a = std::sqrt((T)2);
+        const T inv_sqrt_a = (T)1 / sqrt_a;
+        a.gw_term1 = sqrt_a - inv_sqrt_a;
+        a.gw_inv_sqrt = inv_sqrt_a;
+        a.dims_minus_one = (T)(D - 1);
+        a.tie_eps = sizeof(T) == 8 ? (T)1e-12 : (T)6e-7;
+        a.n = n;
+        a.dims = D;
+        a.color = color;
+        a.shard_begin = shard_begin;
+        a.shard_count = shard_count;
+        a.passes = passes;
+        a.vec_ok = vec_ok;
+        a.n_is_pow2 = (n & (n - 1)) == 0;
+        a.direct_save_slot = -1;
+        a.use_ctl_save = 1;
+        return a;
+    }
+
+    // device StepCtl[0] <- {stream position of half-step `half_steps`, counters}; half_steps must be even
+    int write_ctl(uint64_t step_in_run)
+    {
+        StepCtl* c = (StepCtl*)((char*)h_pinned + 128);
+        const Affine128 j = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps);
+        c->state = apply(j, state0);
+        c->half_step = half_steps;
+        c->step_in_run = step_in_run;
+        HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MCMCPP_HIP_OK;
+    }
+
+    void enqueue_step()
+    {
+        half_fn(args_red, grid_blocks(), stream);
+        half_fn(args_blk, grid_blocks(), stream);
+    }
+
+    int ensure_graphs()
+    {
+        if (graph_steps < 1 || exec_many) return MCMCPP_HIP_OK;
+        for (int which = 0; which < 2; ++which)
+        {
+            const int steps = which == 0 ? graph_steps : 1;
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+            for (int s = 0; s < steps; ++s) enqueue_step();
+            HIP_TRY(hipStreamEndCapture(stream, &g));
+            hipGraphExec_t ex = nullptr;
+            HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(g));
+            (which == 0 ? exec_many : exec_one) = ex;
+        }
+        return MCMCPP_HIP_OK;
+    }
+
+    int launch_steps(int64_t steps)
+    {
+        args_red = make_args(0);
+        args_blk = make_args(1);
+        int rc = ensure_graphs();
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev_start, stream));
+        int64_t left = steps;
+        if (graph_steps >= 1)
+        {
+            while (left >= graph_steps)
+            {
+                HIP_TRY(hipGraphLaunch(exec_many, stream));
+                left -= graph_steps;
+            }
+            while (left > 0)
+            {
+                HIP_TRY(hipGraphLaunch(exec_one, stream));
+                --left;
+            }
+        }
+        else
+        {
+            for (; left > 0; --left) enqueue_step();
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(ev_stop, stream));
+        HIP_TRY(hipEventSynchronize(ev_stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_start, ev_stop));
+        last_ms += ms;
+        last_launches += 2 * steps;
+        half_steps += 2 * (uint64_t)steps;
+        steps_since_reset += (uint64_t)steps;
+        return MCMCPP_HIP_OK;
+    }
+
+    void release()
+    {
+        if (device >= 0) hipSetDevice(device);
+        if (exec_many) hipGraphExecDestroy(exec_many);
+        if (exec_one) hipGraphExecDestroy(exec_one);
+        if (own_pos && d_pos) hipFree(d_pos);
+        if (d_logp) hipFree(d_logp);
+        if (d_nacc) hipFree(d_nacc);
+        if (d_ctl) hipFree(d_ctl);
+        if (d_run) hipFree(d_run);
+        if (d_diag) hipFree(d_diag);
+        if (d_params) hipFree(d_params);
+        if (d_jump_lo) hipFree(d_jump_lo);
+        if (d_jump_hi) hipFree(d_jump_hi);
+        if (h_pinned) hipHostFree(h_pinned);
+        if (ev_start) hipEventDestroy(ev_start);
+        if (ev_stop) hipEventDestroy(ev_stop);
+        if (own_stream && stream) hipStreamDestroy(stream);
+    }
+
+    mcmcpp_hip_config cfg;
+    const LaunchTable<T>* table = nullptr;
+    typename LaunchTable<T>::HalfStepFn half_fn = nullptr;
+    typename LaunchTable<T>::CalcFn calc_fn = nullptr;
+    int W = 0, D = 0, n = 0, lpw = 1, epl = 1, passes = 1, vec_ok = 0, num_cus = 256;
+    int shard_begin = 0, shard_count = 0, device = -1, graph_steps = 32;
+    size_t chain_chunk_bytes = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false, own_pos = false, have_state = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr;
+    uint32_t* d_nacc = nullptr;
+    StepCtl* d_ctl = nullptr;
+    RunInfo* d_run = nullptr;
+    Diag* d_diag = nullptr;
+    Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr;
+    void* h_pinned = nullptr;
+    U128 state0, inc;
+    Affine128 half_jump;
+    HalfStepArgs<T> args_red, args_blk;
+    hipGraphExec_t exec_many = nullptr, exec_one = nullptr;
+    uint64_t half_steps = 0, steps_since_reset = 0;
+    double last_ms = 0.0;
+    int64_t last_launches = 0;
+    void* bound_chain = nullptr;
+    int64_t bound_slots = 0;
+};
+
+int check_config(const mcmcpp_hip_config* c, std::string& err)
+{
+    char buf[256];
+#define BAD(...)                              \
+    do                                        \
+    {                                         \
+        snprintf(buf, sizeof buf, __VA_ARGS__); \
+        err = buf;                            \
+        return MCMCPP_HIP_E_ARG;              \
+    } while (0)
+    if (!c) BAD("config is NULL");
+    if (c->struct_size != sizeof(mcmcpp_hip_config)) BAD("struct_size %u != %zu (ABI mismatch)", c->struct_size, sizeof(mcmcpp_hip_config));
+    if (c->dtype != MCMCPP_HIP_F64 && c->dtype != MCMCPP_HIP_F32) BAD("dtype must be MCMCPP_HIP_F64 or MCMCPP_HIP_F32");
+    if (c->num_params < 1 || c->num_params > 1024) BAD("num_params must be in 1..1024");
+    // EnsembleSampler.h:207-208
+    if (c->num_walkers < 2 || (c->num_walkers & 1)) BAD("num_walkers must be even");
+    if (c->num_walkers <= 2 * c->num_params) BAD("num_walkers must exceed 2*num_params");
+    switch (c->calc_id)
+    {
+    case MCMCPP_HIP_CALC_ISO_GAUSSIAN:
+        if (c->calc_params_len != 0) BAD("IsoGaussian takes no parameters");
+        break;
+    case MCMCPP_HIP_CALC_DENSE_GAUSSIAN:
+        if (!c->calc_params || c->calc_params_len != c->num_params * c->num_params) BAD("DenseGaussian needs D*D parameters");
+        break;
+    case MCMCPP_HIP_CALC_ROSENBROCK:
+        if (!c->calc_params || c->calc_params_len != 3) BAD("Rosenbrock needs 3 parameters (a, b, c)");
+        break;
+    case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D:
+        if (!c->calc_params || c->calc_params_len != 1 || c->num_params != 2) BAD("SkewedGaussian2D needs D == 2 and 1 parameter");
+        break;
+    default: BAD("unknown calc_id %d", c->calc_id);
+    }
+    if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
+#undef BAD
+    return MCMCPP_HIP_OK;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+extern "C"
+{
+int mcmcpp_hip_abi_version(void) { return MCMCPP_HIP_ABI_VERSION; }
+
+int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out)
+{
+    if (!out)
+    {
+        g_create_error = "out is NULL";
+        return MCMCPP_HIP_E_ARG;
+    }
+    *out = nullptr;
+    int rc = check_config(cfg, g_create_error);
+    if (rc) return rc;
+    mcmcpp_hip_sampler* h = nullptr;
+    int irc;
+    if (cfg->dtype == MCMCPP_HIP_F64)
+    {
+        Sampler<double>* s = new (std::nothrow) Sampler<double>();
+        if (!s) return MCMCPP_HIP_E_NOMEM;
+        irc = s->init(*cfg);
+        h = s;
+    }
+    else
+    {
+        Sampler<float>* s = new (std::nothrow) Sampler<float>();
+        if (!s) return MCMCPP_HIP_E_NOMEM;
+        irc = s->init(*cfg);
+        h = s;
+    }
+    if (irc)
+    {
+        g_create_error = h->error;
+        delete h;
+        return irc;
+    }
+    *out = h;
+    return MCMCPP_HIP_OK;
+}
+
+void mcmcpp_hip_destroy(mcmcpp_hip_sampler* h) { delete h; }
+
+const char* mcmcpp_hip_last_error(const mcmcpp_hip_sampler* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+#define NEED_H \
+    if (!h) return MCMCPP_HIP_E_ARG
+
+int mcmcpp_hip_set_state(mcmcpp_hip_sampler* h, const void* positions, const void* logp)
+{
+    NEED_H;
+    return h->set_state(positions, logp);
+}
+int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+{
+    NEED_H;
+    return h->run(n_saved, interval, chain_out, accepted_per_step);
+}
+int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept)
+{
+    NEED_H;
+    return h->get_state(positions, logp, n_accept);
+}
+int mcmcpp_hip_reset_counters(mcmcpp_hip_sampler* h)
+{
+    NEED_H;
+    return h->reset_counters();
+}
+int mcmcpp_hip_get_counters(mcmcpp_hip_sampler* h, uint64_t* accepted, uint64_t* ensemble_steps, uint64_t* near_ties,
+                            uint64_t* redraws)
+{
+    NEED_H;
+    return h->get_counters(accepted, ensemble_steps, near_ties, redraws);
+}
+int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t count, void* logp_out)
+{
+    NEED_H;
+    return h->calc_logp(positions, count, logp_out);
+}
+int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* half_step_launches)
+{
+    NEED_H;
+    return h->last_run_timing(gpu_ms, half_step_launches);
+}
+int mcmcpp_hip_half_step_async(mcmcpp_hip_sampler* h, int32_t color, int64_t save_slot)
+{
+    NEED_H;
+    return h->half_step_async(color, save_slot);
+}
+int mcmcpp_hip_bind_device_chain(mcmcpp_hip_sampler* h, void* device_chain, int64_t slots)
+{
+    NEED_H;
+    return h->bind_device_chain(device_chain, slots);
+}
+void* mcmcpp_hip_device_positions(mcmcpp_hip_sampler* h) { return h ? h->device_positions() : nullptr; }
+int mcmcpp_hip_shard_span(mcmcpp_hip_sampler* h, int32_t color, int64_t* offset_elems, int64_t* count_elems)
+{
+    NEED_H;
+    return h->shard_span(color, offset_elems, count_elems);
+}
+int mcmcpp_hip_synchronize(mcmcpp_hip_sampler* h)
+{
+    NEED_H;
+    return h->synchronize();
+}
+}

@@ -1,0 +1,240 @@
+"""GPU parity tests: the HIP path (through the C ABI of libmcmcpp_hip.so) against the reference's golden
+vectors and against the oracle on the same seeded inputs.
+
+Bar: bit-exact positions, log-posteriors, per-step accepted counts and per-walker counters.  The only
+quantities that may differ in the last ulp between device and host are the two `log` calls feeding the
+accept comparison (StretchMove.h:110,113; OCML vs glibc); they are never stored, and a decision they
+could flip is counted by both sides as a `near_tie` -- every case below asserts there were none, so
+equality is exact, not approximate."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mcmcpp_amd import capi
+from oracle import pyoracle as po
+from tests.goldens import DIGEST, GOLDEN_DIR, SMALL, Golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _params_for(calc, D, t, rng):
+    if calc == po.CALC_DENSE_GAUSSIAN:
+        a = rng.standard_normal((D, D))
+        return (a @ a.T / D + np.eye(D)).astype(t).ravel()
+    if calc == po.CALC_ROSENBROCK:
+        return np.array([1.0, 100.0, 0.05], dtype=t)
+    if calc == po.CALC_SKEWED_GAUSSIAN_2D:
+        return np.array([0.13], dtype=t)
+    return None
+
+
+@pytest.mark.parametrize("dtype", [po.F64, po.F32])
+@pytest.mark.parametrize("calc,D", [(po.CALC_ISO_GAUSSIAN, 1), (po.CALC_ISO_GAUSSIAN, 2), (po.CALC_ISO_GAUSSIAN, 7),
+                                    (po.CALC_ISO_GAUSSIAN, 32), (po.CALC_ISO_GAUSSIAN, 100),
+                                    (po.CALC_ISO_GAUSSIAN, 513), (po.CALC_ISO_GAUSSIAN, 1024),
+                                    (po.CALC_DENSE_GAUSSIAN, 3), (po.CALC_DENSE_GAUSSIAN, 32),
+                                    (po.CALC_DENSE_GAUSSIAN, 64), (po.CALC_DENSE_GAUSSIAN, 130),
+                                    (po.CALC_ROSENBROCK, 2), (po.CALC_ROSENBROCK, 5), (po.CALC_ROSENBROCK, 32),
+                                    (po.CALC_ROSENBROCK, 33), (po.CALC_ROSENBROCK, 300),
+                                    (po.CALC_SKEWED_GAUSSIAN_2D, 2)])
+def test_device_calculators_bit_exact(calc, D, dtype):
+    t = po.np_dtype(dtype)
+    rng = np.random.default_rng(D * 7 + calc)
+    W = 2 * D + 2 + (2 * D) % 2
+    params = _params_for(calc, D, t, rng)
+    pos = (rng.standard_normal((301, D)) * 1.5).astype(t)
+    want = po.Oracle(W, D, calc, params, dtype=dtype).logp(pos)
+    got = capi.HipSampler(W, D, calc, params, dtype=dtype).calc_logp(pos)
+    np.testing.assert_array_equal(got, want)
+
+
+def _run_hip_against_golden(g, **kw):
+    s = capi.HipSampler(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype, **kw)
+    s.set_state(g.init_pos, g.init_logp)
+    done, acc_calls = 0, []
+    for k in sorted(set(g.checked_steps + [g.steps])):
+        chain, acc = s.run(k - done, interval=g.slicing)
+        acc_calls.append(acc.reshape(k - done, g.slicing).sum(axis=1))
+        done = k
+        if k in g.checked_steps:
+            g.check_chain_step(k, chain[-1])
+    np.testing.assert_array_equal(np.concatenate(acc_calls), g.accepted_per_call)
+    c = s.counters()
+    assert c["accepted"] + g.W == g.accepted_total          # reference counts the initial placement
+    assert g.W * (1 + c["ensemble_steps"]) == g.total_steps
+    assert c["near_ties"] == 0 and c["redraws"] == 0
+    return s
+
+
+@pytest.mark.parametrize("name", SMALL + DIGEST)
+def test_hip_matches_reference_golden(name):
+    _run_hip_against_golden(Golden(name))
+
+
+@pytest.mark.parametrize("name", ["iso100x7", "dense96x16", "skewed320x2"])
+def test_hip_matches_reference_golden_without_graphs(name):
+    _run_hip_against_golden(Golden(name), graph_steps=-1)
+
+
+def _oracle_and_hip(W, D, calc, dtype, seed, steps, interval=1, salt=3, **kw):
+    t = po.np_dtype(dtype)
+    rng = np.random.default_rng(W + D)
+    params = _params_for(calc, D, t, rng)
+    orc = po.Oracle(W, D, calc, params, seed=seed, dtype=dtype)
+    pos = po.init_positions(dtype, W, D, salt=salt)
+    logp = orc.logp(pos)
+    orc.set_state(pos, logp)
+    hip = capi.HipSampler(W, D, calc, params, seed=seed, dtype=dtype, **kw)
+    hip.set_state(pos, logp)
+    return orc, hip
+
+
+def _assert_same_state(orc, hip):
+    for a, b, what in zip(hip.get_state(), orc.get_state(), ("positions", "logp", "n_accept")):
+        np.testing.assert_array_equal(a, b, err_msg=what)
+    c = hip.counters()
+    assert c["near_ties"] == 0 == orc.near_ties and c["redraws"] == orc.redraws == 0
+
+
+@pytest.mark.parametrize("W,D,calc,dtype,steps,interval", [
+    (34, 3, po.CALC_ISO_GAUSSIAN, po.F64, 200, 1),       # smallest legal ensembles, odd D (scalar row access)
+    (6, 2, po.CALC_ISO_GAUSSIAN, po.F64, 500, 1),        # n = 3: non power of two partner bound
+    (4, 1, po.CALC_ISO_GAUSSIAN, po.F32, 500, 3),        # D = 1: (D-1) ln z == 0
+    (1026, 512, po.CALC_ISO_GAUSSIAN, po.F64, 12, 1),    # EPL > 2 path (D > 128)
+    (2100, 1024, po.CALC_ISO_GAUSSIAN, po.F32, 6, 1),    # maximum D
+    (300, 64, po.CALC_DENSE_GAUSSIAN, po.F64, 40, 2),
+    (150, 64, po.CALC_DENSE_GAUSSIAN, po.F32, 40, 1),
+    (700, 130, po.CALC_DENSE_GAUSSIAN, po.F64, 8, 1),
+    (4098, 32, po.CALC_ROSENBROCK, po.F32, 30, 1),       # ragged last wavefront
+    (1000, 9, po.CALC_ROSENBROCK, po.F64, 60, 4),
+])
+def test_hip_equals_oracle_fresh_cases(W, D, calc, dtype, steps, interval):
+    orc, hip = _oracle_and_hip(W, D, calc, dtype, seed=12345, steps=steps, interval=interval)
+    oc, oa = orc.run(steps, interval=interval, mode=po.MODE_COUNTER, threads=4)
+    hc, ha = hip.run(steps, interval=interval)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip)
+
+
+def test_seed_and_stream_are_honoured():
+    for seed, stream in [(-7 & (2**64 - 1), 0), (2**40 + 1, 5)]:
+        t = np.float64
+        orc = po.Oracle(128, 8, po.CALC_ISO_GAUSSIAN, None, seed=seed, stream=stream)
+        pos = po.init_positions(po.F64, 128, 8, salt=1)
+        logp = orc.logp(pos)
+        orc.set_state(pos, logp)
+        hip = capi.HipSampler(128, 8, po.CALC_ISO_GAUSSIAN, None, seed=seed, stream=stream)
+        hip.set_state(pos, logp)
+        oc, oa = orc.run(50)
+        hc, ha = hip.run(50)
+        np.testing.assert_array_equal(hc, oc)
+        np.testing.assert_array_equal(ha, oa)
+
+
+def test_resume_reset_and_unsaved_runs_are_seamless():
+    orc, hip = _oracle_and_hip(512, 16, po.CALC_ROSENBROCK, po.F64, seed=3, steps=0)
+    oc, oa = orc.run(90)
+    c1, a1 = hip.run(20)
+    _, a2 = hip.run(5, interval=2, save_chain=False)           # 10 unsaved-to-host steps
+    hip.reset_counters()                                       # EnsembleSampler::reset keeps positions/stream
+    assert hip.counters()["accepted"] == 0 and hip.counters()["ensemble_steps"] == 0
+    c3, a3 = hip.run(60, want_accepted=False)
+    np.testing.assert_array_equal(c1, oc[:20])
+    np.testing.assert_array_equal(c3, oc[30:])
+    np.testing.assert_array_equal(np.concatenate([a1, a2]), oa[:30])
+    assert a3 is None
+    pos, logp, nacc = hip.get_state()
+    opos, ologp, onacc = orc.get_state()
+    np.testing.assert_array_equal(pos, opos)
+    np.testing.assert_array_equal(logp, ologp)
+    assert int(nacc.sum()) == int(oa[30:].sum())               # counters restarted at the reset
+
+
+def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
+    base = None
+    for env in [{}, {"MCMCPP_HIP_PASSES": "1"}, {"MCMCPP_HIP_PASSES": "4"}, {"MCMCPP_HIP_PASSES": "16"},
+                {"MCMCPP_HIP_CHAIN_CHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"}]:
+        for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_CHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        orc, hip = _oracle_and_hip(2048 + 2, 32, po.CALC_DENSE_GAUSSIAN, po.F64, seed=9, steps=0)
+        chain, acc = hip.run(25)
+        state = hip.get_state()
+        if base is None:
+            oc, oa = orc.run(25, mode=po.MODE_COUNTER, threads=4)
+            np.testing.assert_array_equal(chain, oc)
+            np.testing.assert_array_equal(acc, oa)
+            base = (chain, acc, state)
+        else:
+            np.testing.assert_array_equal(chain, base[0])
+            np.testing.assert_array_equal(acc, base[1])
+            for a, b in zip(state, base[2]):
+                np.testing.assert_array_equal(a, b)
+
+
+def test_hip_reproduces_reference_own_test_run():
+    """The reference's SkewedGaussian/StretchMove test end to end: 320 x 2, slicing 30, 40 019 stored steps
+    (1.2 M ensemble steps); accepted/total exactly as the reference prints them."""
+    want = json.load(open(os.path.join(GOLDEN_DIR, "reference_skewed_test.json")))
+    g = Golden("skewed320x2")
+    s = capi.HipSampler(g.W, g.D, g.calc, g.params, seed=0)
+    s.set_state(g.init_pos, g.init_logp)
+    chain, _ = s.run(want["stored_steps"], interval=want["slicing"], want_accepted=False)
+    c = s.counters()
+    assert c["near_ties"] == 0
+    assert c["accepted"] + g.W == want["accepted_total"]
+    assert g.W * (1 + c["ensemble_steps"]) == want["total_steps"]
+    # sliceAndBurnChain(1, 20) then covariance, as the reference's main does (analytic: 1.13, 0.435, 0.2825)
+    x = chain[20:].reshape(-1, 2)
+    cov = np.cov(x.T)
+    assert abs(cov[0, 0] - 1.13) < 0.02 and abs(cov[0, 1] - 0.435) < 0.01 and abs(cov[1, 1] - 0.2825) < 0.005
+
+
+# ---- BASELINE.json full sizes ---------------------------------------------------------------------------
+
+def test_config3_full_size_against_oracle():
+    """65 536 walkers x 32-dim Rosenbrock (BASELINE config 3): 6 steps against the multi-threaded oracle."""
+    orc, hip = _oracle_and_hip(65536, 32, po.CALC_ROSENBROCK, po.F64, seed=0, steps=0, salt=0)
+    oc, oa = orc.run(6, mode=po.MODE_COUNTER, threads=8)
+    hc, ha = hip.run(6)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip)
+
+
+def test_config5_shape_single_gpu_against_oracle():
+    """131 072 walkers x 64-dim Gaussian (BASELINE config 5's ensemble) on one GPU: 3 steps."""
+    orc, hip = _oracle_and_hip(131072, 64, po.CALC_ISO_GAUSSIAN, po.F64, seed=0, steps=0, salt=0)
+    oc, oa = orc.run(3, mode=po.MODE_COUNTER, threads=8)
+    hc, ha = hip.run(3)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip)
+
+
+def test_config2_statistical_properties_long_run():
+    """16 384 x 32 correlated Gaussian (BASELINE config 2), 600 steps: size-independent checks --
+    acceptance in the stretch-move range for D = 32, and the sample covariance of the last stored steps
+    approaches Sigma_ij = 0.5^|i-j| (the target's covariance)."""
+    D, W = 32, 16384
+    P = np.zeros((D, D))
+    rho = 0.5
+    d = 1 - rho * rho
+    for i in range(D):
+        P[i, i] = (1.0 if i in (0, D - 1) else 1 + rho * rho) / d
+        if i + 1 < D:
+            P[i, i + 1] = P[i + 1, i] = -rho / d
+    hip = capi.HipSampler(W, D, capi.CALC_DENSE_GAUSSIAN, P.ravel(), seed=1)
+    pos = po.init_positions(po.F64, W, D, salt=0)
+    hip.set_state(pos, hip.calc_logp(pos))
+    hip.run(1, interval=500, save_chain=False)
+    chain, acc = hip.run(2, interval=50)
+    rate = acc.mean() / W
+    assert 0.2 < rate < 0.45, rate
+    cov = np.cov(chain.reshape(-1, D).T)
+    sigma = rho ** np.abs(np.subtract.outer(np.arange(D), np.arange(D)))
+    assert np.abs(cov - sigma).max() < 0.06, np.abs(cov - sigma).max()
