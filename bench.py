@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- walker-steps/s of the stretch-move ensemble step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 16 384 walkers x 32 dims, correlated Gaussian
+log-posterior (Sigma_ij = 0.5^|i-j|, dense 32x32 precision matrix), fp64, StretchMove, seed = rank.
+One bench "step" = one runMCMC batch of `--batch` ensemble steps (default 1000: 10 stored steps at
+slicing interval 100, stored steps downloaded to the host inside the timed region; everything else stays
+resident in HBM).  For N > 1 every rank runs its own independent chain of the same size on its own GPU
+(BASELINE.json configs[3]: no data-path collective; weak scaling); the value is the sum over ranks
+divided by the slowest rank's time.
+
+The JSON line also carries
+  roofline      achieved HBM bytes/s of the dominant kernel: algorithmic bytes per half-step launch
+                ((2D+1)*8 read + (D+1)*8 written per walker update = 784 B at D = 32, x 8192
+                walkers per launch) / the average launch duration measured with HIP events on the launch
+                stream around the replayed launches (mcmcpp_hip_last_run_timing)
+  cpu_baseline  the reference itself (oracle/_ref, kind "reference") or the oracle ("port") timed on this
+                host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def ar1_precision(D, rho):
+    P = np.zeros((D, D))
+    d = 1.0 - rho * rho
+    for i in range(D):
+        P[i, i] = (1.0 if i in (0, D - 1) else 1.0 + rho * rho) / d
+        if i + 1 < D:
+            P[i, i + 1] = P[i + 1, i] = -rho / d
+    return P
+
+
+def cpu_baseline(W, D, P, sample_steps):
+    """Time the CPU path on a bounded sample of the workload.  oracle/ is used here only as the measured
+    baseline, never by the GPU path."""
+    from oracle import pyoracle as po
+    # the GPU box gives one GPU job a share of 16 host cores (gpurun notes); more threads only thrash
+    cores = min(len(os.sched_getaffinity(0)) or 1, 16)
+    pos = po.init_positions(po.F64, W, D, salt=0)
+    orc = po.Oracle(W, D, po.CALC_DENSE_GAUSSIAN, P.ravel(), seed=0)
+    logp = orc.logp(pos)
+    out = {}
+    if po.reference_available():
+        # MCMC::EnsembleSampler of the reference, one thread, slicing so that only one step is stored
+        r = po.reference_run(W, D, po.CALC_DENSE_GAUSSIAN, P.ravel(), 0, pos, logp, 1, 1, slicing=sample_steps,
+                             want_chain=False)
+        out = dict(value=W * sample_steps / r["seconds"], unit="walker-steps/s", cores=1, kind="reference",
+                   sample="MCMC::EnsembleSampler<double, StretchMove> (reference, 1 thread): %d ensemble steps of "
+                          "the %dx%d workload, %.1f s" % (sample_steps, W, D, r["seconds"]))
+    # the oracle on all cores (static walker partition): the fair analogue of ParallelEnsembleSampler
+    orc.set_state(pos, logp)
+    orc.run(1, interval=2, save_chain=False, mode=po.MODE_COUNTER, threads=cores)  # start the thread pool
+    orc.set_state(pos, logp)
+    t0 = time.perf_counter()
+    orc.run(1, interval=sample_steps, save_chain=False, mode=po.MODE_COUNTER, threads=cores)
+    dt = time.perf_counter() - t0
+    port = dict(value=W * sample_steps / dt, unit="walker-steps/s", cores=cores, kind="port",
+                sample="oracle, %d threads: %d ensemble steps of the %dx%d workload, %.1f s"
+                       % (cores, sample_steps, W, D, dt))
+    if not out:
+        out = port
+    else:
+        out["all_cores_port"] = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1000, help="ensemble steps per bench step")
+    ap.add_argument("--interval", type=int, default=100, help="slicing interval (one stored step per interval)")
+    ap.add_argument("--walkers", type=int, default=16384)
+    ap.add_argument("--dims", type=int, default=32)
+    ap.add_argument("--cpu-sample-steps", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
+    ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
+                    help="experiments only: the headline workload is the dense (correlated) Gaussian")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mcmcpp_amd import capi
+    from oracle import pyoracle as po  # initial positions only (pure integer-hash recipe)
+
+    W, D = args.walkers, args.dims
+    assert args.batch % args.interval == 0
+    n_saved = args.batch // args.interval
+    P = ar1_precision(D, 0.5)
+    calc_id, calc_params = {"dense": (capi.CALC_DENSE_GAUSSIAN, P.ravel()), "iso": (capi.CALC_ISO_GAUSSIAN, None),
+                            "rosenbrock": (capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05])}[args.calc]
+    sampler = capi.HipSampler(W, D, calc_id, calc_params, seed=rank, device=local_rank)
+    pos = po.init_positions(po.F64, W, D, salt=rank)
+    sampler.set_state(pos, sampler.calc_logp(pos))
+
+    def bench_step():
+        return sampler.run(n_saved, interval=args.interval, save_chain=True, want_accepted=not args.no_accepted)
+
+    for _ in range(args.warmup):
+        bench_step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    accepted = 0
+    gpu_ms = 0.0
+    launches = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, acc = bench_step()
+        accepted += int(acc.sum()) if acc is not None else 0
+        ms, nl = sampler.last_run_timing()
+        gpu_ms += ms
+        launches += nl
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    walker_steps = float(W) * args.batch * args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([walker_steps, float(accepted), gpu_ms, float(launches)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        walker_steps, accepted, gpu_ms, launches = [float(x) for x in s.tolist()]
+
+    if rank == 0:
+        bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8          # 784 B at D = 32, fp64
+        saved_fraction = 1.0 / args.interval
+        bytes_per_launch = (W // 2) * (bytes_per_update + saved_fraction * D * 8)
+        us_per_launch = gpu_ms * 1e3 / launches
+        achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+        line = {
+            "metric": "walker-steps/sec + acceptance rate, 16384 walkers x 32 dims, 1/2/4/8 GPU",
+            "value": walker_steps / elapsed,
+            "unit": "walker-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "acceptance_rate": accepted / walker_steps,
+            "config": {"workload": "C2: %d walkers x %d dims, correlated Gaussian (rho=0.5, dense precision), "
+                                   "StretchMove, fp64; one step = %d ensemble steps, 1 stored step per %d "
+                                   "downloaded; %s" % (W, D, args.batch, args.interval,
+                                                       "one independent chain per GPU (seed = rank)" if world > 1
+                                                       else "one chain"),
+                       "walkers": W, "dims": D, "ensemble_steps_per_step": args.batch,
+                       "slicing_interval": args.interval, "chains": world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "stretch_half_step_kernel<double, DenseGaussianFn, EPL=2, LPW=16>",
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": us_per_launch,
+                         "note": "avg launch duration = HIP-event time on the launch stream over the graph-replayed "
+                                 "half-step launches / launches; it includes the ~1.5 us dependent-launch boundary"},
+        }
+        if args.calc != "dense":
+            line["config"]["workload"] += " [EXPERIMENT: calculator = %s, not the headline workload]" % args.calc
+        if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
+            line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

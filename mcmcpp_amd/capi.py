@@ -31,7 +31,8 @@ class Config(C.Structure):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmcmcpp_hip.so")
+    # MCMCPP_HIP_LIB: diagnostics only (e.g. the in-kernel-stamp build libmcmcpp_hip_stamps.so)
+    return os.environ.get("MCMCPP_HIP_LIB") or os.path.join(_HERE, "libmcmcpp_hip.so")
 
 
 def build_library(force=False):

@@ -23,6 +23,9 @@ struct LaunchTable
     CalcFn calc[kLpwLevels][kMaxEplShift];
 };
 
+void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream);
+
 // one definition per (element type, calculator), each in its own translation unit
 const LaunchTable<double>* launch_table_f64_iso();
 const LaunchTable<double>* launch_table_f64_dense();

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/mcmcpp_hip.h"
+#define MCMCPP_DEFINE_REDUCE_KERNEL
 #include "launch_table.hpp"
 
 using namespace mcmcpp;
@@ -82,6 +83,16 @@ const LaunchTable<float>* table_for<float>(int calc_id)
 }
 }  // namespace
 
+namespace mcmcpp
+{
+void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream)
+{
+    hipLaunchKernelGGL(accepted_reduce_kernel, dim3((unsigned)count), dim3(256), 0, stream, partials, partial_slots,
+                       partial_waves, count, ctl_after, run);
+}
+}  // namespace mcmcpp
+
 // ---------------------------------------------------------------------------------------------------
 struct mcmcpp_hip_sampler
 {
@@ -99,6 +110,7 @@ struct mcmcpp_hip_sampler
     virtual void* device_positions() = 0;
     virtual int shard_span(int32_t color, int64_t* off, int64_t* cnt) = 0;
     virtual int synchronize() = 0;
+    virtual int debug_stamps(unsigned long long* out8) = 0;
 
     int fail(int code, const char* fmt, ...)
     {
@@ -212,6 +224,10 @@ public:
         HIP_TRY(hipMalloc(&d_ctl, sizeof(StepCtl) * 2));
         HIP_TRY(hipMalloc(&d_run, sizeof(RunInfo)));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
+#ifdef MCMCPP_STAMPS
+        HIP_TRY(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_stamps, 0, 8 * sizeof(unsigned long long)));
+#endif
         HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
         HIP_TRY(hipMemset(d_run, 0, sizeof(RunInfo)));
@@ -249,8 +265,21 @@ public:
             HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
         }
         half_jump = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n);
+        if ((size_t)3 * n * sizeof(Affine128) <= ((size_t)env_long("MCMCPP_HIP_TASK_TABLE_MB", 16) << 20))
+        {
+            std::vector<Affine128> tj((size_t)3 * n);
+            const Affine128 step1 = pcg_jump(inc, 1);
+            tj[0] = step1;
+            for (size_t t = 1; t < tj.size(); ++t) tj[t] = compose(step1, tj[t - 1]);
+            HIP_TRY(hipMalloc(&d_task_jump, sizeof(Affine128) * tj.size()));
+            HIP_TRY(hipMemcpy(d_task_jump, tj.data(), sizeof(Affine128) * tj.size(), hipMemcpyHostToDevice));
+        }
 
         graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 32) : c.graph_steps;
+        partial_slots = graph_steps >= 1 ? graph_steps : 1;
+        partial_waves = (int)grid_blocks() * kWavesPerBlock;
+        HIP_TRY(hipMalloc(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
+        HIP_TRY(hipMemset(d_partials, 0, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
         chain_chunk_bytes = (size_t)env_long("MCMCPP_HIP_CHAIN_CHUNK_MB", 4096) << 20;
         return MCMCPP_HIP_OK;
     }
@@ -419,6 +448,7 @@ public:
         HIP_TRY(hipSetDevice(device));
         HalfStepArgs<T> a = make_args(color);
         a.use_ctl_save = 0;
+        a.partials = nullptr;
         a.direct_save_slot = save_slot;
         half_fn(a, grid_blocks(), stream);
         HIP_TRY(hipGetLastError());
@@ -443,6 +473,14 @@ public:
         if (color != 0 && color != 1) return fail(MCMCPP_HIP_E_ARG, "shard_span: colour must be 0 or 1");
         if (off) *off = ((int64_t)(color ? n : 0) + shard_begin) * D;
         if (cnt) *cnt = (int64_t)shard_count * D;
+        return MCMCPP_HIP_OK;
+    }
+
+    int debug_stamps(unsigned long long* out8) override
+    {
+        if (!d_stamps) return fail(MCMCPP_HIP_E_UNSUPPORTED, "not a diagnostic build");
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(out8, d_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return MCMCPP_HIP_OK;
     }
 
@@ -493,8 +531,10 @@ private:
         a.diag = d_diag;
         a.jump_lo = d_jump_lo;
         a.jump_hi = d_jump_hi;
+        a.task_jump = d_task_jump;
         a.calc_params = d_params;
         a.half_jump = half_jump;
+        for (int k = 0; k < 3; ++k) a.draw_jump[k] = pcg_jump(inc, (unsigned)k + 1);
         a.inc = inc;
         a.redraw_threshold = (uint64_t)(0 - (uint64_t)n) % (uint64_t)n;
         // GwDistribution<T,2,1> (MCMCpp/Utility/GwDistribution.h:45-55)
@@ -512,8 +552,12 @@ private:
         a.passes = passes;
         a.vec_ok = vec_ok;
         a.n_is_pow2 = (n & (n - 1)) == 0;
+        a.partials = d_partials;
+        a.partial_slots = partial_slots;
+        a.partial_waves = partial_waves;
         a.direct_save_slot = -1;
         a.use_ctl_save = 1;
+        a.stamps = d_stamps;
         return a;
     }
 
@@ -525,6 +569,9 @@ private:
         c->state = apply(j, state0);
         c->half_step = half_steps;
         c->step_in_run = step_in_run;
+        c->chain_slot = 0;
+        c->save_phase = 0;
+        c->partial_slot = 0;
         HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         return MCMCPP_HIP_OK;
@@ -545,6 +592,7 @@ private:
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
             for (int s = 0; s < steps; ++s) enqueue_step();
+            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, d_ctl, d_run, stream);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -577,7 +625,11 @@ private:
         }
         else
         {
-            for (; left > 0; --left) enqueue_step();
+            for (; left > 0; --left)
+            {
+                enqueue_step();
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, d_ctl, d_run, stream);
+            }
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev_stop, stream));
@@ -602,9 +654,11 @@ private:
         if (d_ctl) hipFree(d_ctl);
         if (d_run) hipFree(d_run);
         if (d_diag) hipFree(d_diag);
+        if (d_partials) hipFree(d_partials);
         if (d_params) hipFree(d_params);
         if (d_jump_lo) hipFree(d_jump_lo);
         if (d_jump_hi) hipFree(d_jump_hi);
+        if (d_task_jump) hipFree(d_task_jump);
         if (h_pinned) hipHostFree(h_pinned);
         if (ev_start) hipEventDestroy(ev_start);
         if (ev_stop) hipEventDestroy(ev_stop);
@@ -626,7 +680,10 @@ private:
     StepCtl* d_ctl = nullptr;
     RunInfo* d_run = nullptr;
     Diag* d_diag = nullptr;
-    Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr;
+    unsigned long long* d_stamps = nullptr;  // diagnostic build only
+    uint32_t* d_partials = nullptr;
+    int partial_slots = 1, partial_waves = 0;
+    Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_task_jump = nullptr;
     void* h_pinned = nullptr;
     U128 state0, inc;
     Affine128 half_jump;
@@ -682,6 +739,15 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
 extern "C"
 {
 int mcmcpp_hip_abi_version(void) { return MCMCPP_HIP_ABI_VERSION; }
+
+#ifdef MCMCPP_STAMPS
+// diagnostic build only: shader-clock stamps of the last half-step launch (not part of the ABI)
+int mcmcpp_hip_debug_stamps(mcmcpp_hip_sampler* h, unsigned long long* out8)
+{
+    if (!h || !out8) return MCMCPP_HIP_E_ARG;
+    return h->debug_stamps(out8);
+}
+#endif
 
 int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out)
 {

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Diagnostic: where one wavefront of a half-step launch spends its cycles (needs make -C mcmcpp_amd/csrc STAMPS=1)."""
+import ctypes as C, os, sys
+import numpy as np
+os.environ["MCMCPP_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mcmcpp_amd", "libmcmcpp_hip_stamps.so")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mcmcpp_amd import capi
+from oracle import pyoracle as po
+import bench
+names = ["entry->loads landed", "phase A (rng, log)", "partner rows landed", "calculator", "accept+stores drained"]
+for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
+    D = 32
+    P = bench.ar1_precision(D, 0.5)
+    cid, prm = {"dense": (capi.CALC_DENSE_GAUSSIAN, P.ravel()), "iso": (capi.CALC_ISO_GAUSSIAN, None)}[calc]
+    s = capi.HipSampler(W, D, cid, prm, seed=0)
+    pos = po.init_positions(po.F64, W, D)
+    s.set_state(pos, s.calc_logp(pos))
+    acc = []
+    for rep in range(20):
+        s.run(40, save_chain=False, want_accepted=False)
+        out = (C.c_ulonglong * 8)()
+        capi.lib().mcmcpp_hip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+        assert capi.lib().mcmcpp_hip_debug_stamps(s.h, out) == 0
+        t = np.array(list(out)[:6], dtype=np.float64)
+        acc.append(np.diff(t))
+    d = np.median(np.array(acc), axis=0)
+    print(calc, W, " | ".join("%s %.0f" % (n, x) for n, x in zip(names, d)), "| total %.0f ticks (s_memtime)" % d.sum())
