@@ -1,0 +1,61 @@
+/*
+ * Chain/ChainBlock.h -- one contiguous slab of stored ensemble steps.
+ *
+ * Output format kept from the reference (/root/reference/MCMCpp/Chain/ChainBlock.h:125-131): positions
+ * only, cell = step*W*D + walker*D + param, every step holds all W walkers.  Unlike the reference's fixed
+ * 10 000-step blocks indexed with 32-bit int (ChainBlock.h:31,115-123 -- the size product overflows at
+ * 16 384 x 32 and above), a block here is sized in bytes and indexed with 64-bit integers.
+ */
+#ifndef MCMCPP_CHAIN_CHAINBLOCK_H
+#define MCMCPP_CHAIN_CHAINBLOCK_H
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+namespace MCMC
+{
+namespace Chain
+{
+namespace Detail
+{
+/// Default slab size; the number of steps per block follows from it and the ensemble size.
+static const unsigned long long DefaultBlockBytes = 256ULL << 20;
+}
+
+template <class ParamType>
+class ChainBlock
+{
+public:
+    ChainBlock(std::int64_t stepsInBlock, std::int64_t cellsInStep)
+        : capacitySteps(stepsInBlock), cellsPerStep(cellsInStep), usedSteps(0), cells(nullptr)
+    {
+        const std::size_t bytes = static_cast<std::size_t>(capacitySteps) * static_cast<std::size_t>(cellsPerStep) * sizeof(ParamType);
+        // 64-byte alignment like the reference's autoAlignedAlloc (Utility/Misc.h:77-102)
+        void* p = nullptr;
+        if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0) p = nullptr;
+        cells = static_cast<ParamType*>(p);
+    }
+    ~ChainBlock() { std::free(cells); }
+    ChainBlock(const ChainBlock&) = delete;
+    ChainBlock& operator=(const ChainBlock&) = delete;
+
+    bool valid() const { return cells != nullptr; }
+    bool full() const { return usedSteps >= capacitySteps; }
+    std::int64_t capacity() const { return capacitySteps; }
+    std::int64_t used() const { return usedSteps; }
+    void setUsed(std::int64_t n) { usedSteps = n; }
+    ParamType* step(std::int64_t k) { return cells + static_cast<std::size_t>(k) * static_cast<std::size_t>(cellsPerStep); }
+    const ParamType* step(std::int64_t k) const { return cells + static_cast<std::size_t>(k) * static_cast<std::size_t>(cellsPerStep); }
+
+private:
+    std::int64_t capacitySteps;
+    std::int64_t cellsPerStep;
+    std::int64_t usedSteps;
+    ParamType* cells;
+};
+
+}  // namespace Chain
+}  // namespace MCMC
+#endif  // MCMCPP_CHAIN_CHAINBLOCK_H

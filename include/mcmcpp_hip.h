@@ -76,6 +76,10 @@ typedef struct mcmcpp_hip_config {
     int32_t shard_begin;
     int32_t shard_count;
     int32_t graph_steps;     /* ensemble steps per hipGraph replay; 0 = library default, -1 = no graphs */
+    /* stretch scale a = gw_alpha_num / gw_alpha_den of GwDistribution<ParamType, Num, Denom>
+     * (Utility/GwDistribution.h:45-55; StretchMove's default is 2/1); 0/0 selects 2/1 */
+    int32_t gw_alpha_num;
+    int32_t gw_alpha_den;
     void* device_positions;  /* optional caller-owned DEVICE buffer of W*D elements used in place of an
                                 internal one (e.g. memory registered with a collective library) */
     void* hip_stream;        /* optional hipStream_t to launch on; NULL = a stream owned by the handle */

@@ -27,6 +27,7 @@ class Config(C.Structure):
                 ("num_params", C.c_int32), ("calc_id", C.c_int32), ("calc_params_len", C.c_int32),
                 ("calc_params", C.c_void_p), ("seed", C.c_uint64), ("stream", C.c_uint64), ("device", C.c_int32),
                 ("shard_begin", C.c_int32), ("shard_count", C.c_int32), ("graph_steps", C.c_int32),
+                ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32),
                 ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p)]
 
 
@@ -97,13 +98,13 @@ class HipSampler:
     """Thin owner of one mcmcpp_hip_sampler handle (one GPU)."""
 
     def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, device=-1, shard_begin=0,
-                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None):
+                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1)):
         self.W, self.D, self.dtype = W, D, dtype
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self.cfg = Config(C.sizeof(Config), dtype, W, D, calc_id, 0 if self.params is None else self.params.size,
                           _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
-                          shard_count, graph_steps, device_positions, hip_stream)
+                          shard_count, graph_steps, alpha[0], alpha[1], device_positions, hip_stream)
         self.h = C.c_void_p()
         rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
         if rc != OK:

@@ -538,7 +538,8 @@ private:
         a.inc = inc;
         a.redraw_threshold = (uint64_t)(0 - (uint64_t)n) % (uint64_t)n;
         // GwDistribution<T,2,1> (MCMCpp/Utility/GwDistribution.h:45-55)
-        const T sqrt_a = std::sqrt((T)2);
+        const T alpha = (T)(cfg.gw_alpha_num > 0 ? cfg.gw_alpha_num : 2) / (T)(cfg.gw_alpha_den > 0 ? cfg.gw_alpha_den : 1);
+        const T sqrt_a = std::sqrt(alpha);
         const T inv_sqrt_a = (T)1 / sqrt_a;
         a.gw_term1 = sqrt_a - inv_sqrt_a;
         a.gw_inv_sqrt = inv_sqrt_a;
@@ -730,6 +731,9 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
     default: BAD("unknown calc_id %d", c->calc_id);
     }
     if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
+    if (c->gw_alpha_num < 0 || c->gw_alpha_den < 0 || ((c->gw_alpha_num == 0) != (c->gw_alpha_den == 0)))
+        BAD("gw_alpha_num/gw_alpha_den must both be positive (or both 0 for the default 2/1)");
+    if (c->gw_alpha_num > 0 && c->gw_alpha_num <= c->gw_alpha_den) BAD("the stretch scale alpha must exceed 1");
 #undef BAD
     return MCMCPP_HIP_OK;
 }

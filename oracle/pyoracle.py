@@ -27,7 +27,8 @@ def np_dtype(dtype):
 class _Config(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("num_walkers", C.c_int32), ("num_params", C.c_int32),
                 ("calc_id", C.c_int32), ("calc_params", C.c_void_p), ("calc_params_len", C.c_int32),
-                ("reserved", C.c_int32), ("seed", C.c_uint64), ("stream", C.c_uint64)]
+                ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32), ("reserved", C.c_int32),
+                ("seed", C.c_uint64), ("stream", C.c_uint64)]
 
 
 class _Pcg64(C.Structure):
@@ -128,12 +129,12 @@ def init_positions(dtype, W, D, salt=0):
 class Oracle:
     """The CPU restatement of EnsembleSampler + StretchMove."""
 
-    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64):
+    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, alpha=(2, 1)):
         self.W, self.D, self.dtype = W, D, dtype
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self.cfg = _Config(dtype, W, D, calc_id, _ptr(self.params), 0 if self.params is None else self.params.size,
-                           0, seed & (2**64 - 1), stream & (2**64 - 1))
+                           alpha[0], alpha[1], 0, seed & (2**64 - 1), stream & (2**64 - 1))
         self.h = C.c_void_p()
         rc = lib().so_create(C.byref(self.cfg), C.byref(self.h))
         if rc:
@@ -197,7 +198,7 @@ def ref_lib():
     if _ref is None:
         build()
         R = C.CDLL(os.path.join(_HERE, "_ref", "libmcmcpp_ref.so"))
-        R.ref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+        R.ref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
                               C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         R.ref_skewed_initial_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
@@ -207,8 +208,9 @@ def ref_lib():
 
 
 def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_call, slicing=1, want_chain=True,
-                  threads=0, dtype=F64):
+                  threads=0, dtype=F64, alpha_code=0):
     """Run MCMC::EnsembleSampler (threads=0) or ParallelEnsembleSampler (threads>=1) of the reference.
+    alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>.
 
     Returns dict(chain[(stored, W, D)] incl. step 0 = initial placement, accepted[n_calls], total[n_calls],
     stored, seconds, fraction)."""
@@ -223,7 +225,7 @@ def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_cal
     stored = C.c_int(0)
     secs = C.c_double(0)
     frac = C.c_double(0)
-    rc = ref_lib().ref_run(dtype, threads, W, D, calc_id, _ptr(prm), seed, _ptr(pos), _ptr(logp), n_calls,
+    rc = ref_lib().ref_run(dtype, threads, alpha_code, W, D, calc_id, _ptr(prm), seed, _ptr(pos), _ptr(logp), n_calls,
                            steps_per_call, slicing, _ptr(chain), cap, _ptr(acc), _ptr(tot), C.byref(stored),
                            C.byref(secs), C.byref(frac))
     if rc < 0:

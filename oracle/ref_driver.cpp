@@ -29,13 +29,13 @@ using arrow_vendored::pcg64;
 
 namespace
 {
-template <class T, class Calc>
+template <class T, class Calc, class Dist>
 int runSequential(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
                   int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
                   unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
                   double* seconds)
 {
-    typedef MCMC::Mover::StretchMove<T, Calc> MoverType;
+    typedef MCMC::Mover::StretchMove<T, Calc, Dist> MoverType;
     MoverType mover(D, seed, calc);
     MCMC::EnsembleSampler<T, MoverType> sampler(seed, W, D, mover);
     if (slicing > 1) sampler.setSlicingMode(true, slicing);
@@ -78,14 +78,19 @@ int runParallel(Calc& calc, int threads, int W, int D, int seed, const T* initPo
 }
 
 template <class T>
-int dispatch(int calcId, int threads, int W, int D, const T* params, int seed, const T* initPos, const T* initLogp,
+int dispatch(int calcId, int threads, int alphaCode, int W, int D, const T* params, int seed, const T* initPos, const T* initLogp,
              int nCalls, int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
              unsigned long long* acc, unsigned long long* tot, int* stored, double* seconds, double* fraction)
 {
 #define MCMCPP_REF_GO(CALC)                                                                                        \
+    if (threads <= 0 && alphaCode == 1)                                                                            \
+        return runSequential<T, decltype(CALC), MCMC::Utility::GwDistribution<T, 3, 2> >(                          \
+            CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acc, \
+            tot, stored, seconds);                                                                                 \
     if (threads <= 0)                                                                                              \
-        return runSequential<T>(CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut,      \
-                                chainCapacitySteps, acc, tot, stored, seconds);                                    \
+        return runSequential<T, decltype(CALC), MCMC::Utility::GwDistribution<T, 2, 1> >(                          \
+            CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acc, \
+            tot, stored, seconds);                                                                                 \
     return runParallel<T>(CALC, threads, W, D, seed, initPos, initLogp, nCalls * stepsPerCall, seconds, fraction)
     switch (calcId)
     {
@@ -124,19 +129,20 @@ extern "C"
 {
 /* threads <= 0: MCMC::EnsembleSampler; threads >= 1: MCMC::ParallelEnsembleSampler (timing only:
  * it is non-deterministic above one thread, ParallelEnsembleSampler.h:71-76).
+ * alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>.
  * dtype 0 = double, 1 = float.  chain_out holds up to chain_capacity_steps steps of W*D values
  * (chain step 0 is the initial placement, EnsembleSampler.h:228-229). */
-int ref_run(int dtype, int threads, int W, int D, int calc_id, const void* params, int seed, const void* init_pos,
+int ref_run(int dtype, int threads, int alpha_code, int W, int D, int calc_id, const void* params, int seed, const void* init_pos,
             const void* init_logp, int n_calls, int steps_per_call, int slicing, void* chain_out,
             long long chain_capacity_steps, unsigned long long* accepted_after_call,
             unsigned long long* total_after_call, int* stored_steps, double* seconds, double* fraction)
 {
     if (dtype == 0)
-        return dispatch<double>(calc_id, threads, W, D, static_cast<const double*>(params), seed,
+        return dispatch<double>(calc_id, threads, alpha_code, W, D, static_cast<const double*>(params), seed,
                                 static_cast<const double*>(init_pos), static_cast<const double*>(init_logp), n_calls,
                                 steps_per_call, slicing, static_cast<double*>(chain_out), chain_capacity_steps,
                                 accepted_after_call, total_after_call, stored_steps, seconds, fraction);
-    return dispatch<float>(calc_id, threads, W, D, static_cast<const float*>(params), seed,
+    return dispatch<float>(calc_id, threads, alpha_code, W, D, static_cast<const float*>(params), seed,
                            static_cast<const float*>(init_pos), static_cast<const float*>(init_logp), n_calls,
                            steps_per_call, slicing, static_cast<float*>(chain_out), chain_capacity_steps,
                            accepted_after_call, total_after_call, stored_steps, seconds, fraction);

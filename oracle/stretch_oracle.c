@@ -144,6 +144,7 @@ struct so_sampler {
 #define REAL double
 #define SFX(n) n##_f64
 #define LOG(x) log(x)
+#define SQRT(x) sqrt(x)
 #define FMA(a, b, c) fma(a, b, c)
 #define FABS(x) fabs(x)
 #define CANON(r) so_canonical_f64(r)
@@ -152,6 +153,7 @@ struct so_sampler {
 #undef REAL
 #undef SFX
 #undef LOG
+#undef SQRT
 #undef FMA
 #undef FABS
 #undef CANON
@@ -160,6 +162,7 @@ struct so_sampler {
 #define REAL float
 #define SFX(n) n##_f32
 #define LOG(x) logf(x)
+#define SQRT(x) sqrtf(x)
 #define FMA(a, b, c) fmaf(a, b, c)
 #define FABS(x) fabsf(x)
 #define CANON(r) so_canonical_f32(r)
@@ -168,6 +171,7 @@ struct so_sampler {
 #undef REAL
 #undef SFX
 #undef LOG
+#undef SQRT
 #undef FMA
 #undef FABS
 #undef CANON

@@ -55,6 +55,8 @@ typedef struct so_config {
     int32_t calc_id;     /* SO_CALC_* */
     const void* calc_params; /* array of dtype elements, may be NULL when the calculator has none */
     int32_t calc_params_len; /* number of elements in calc_params */
+    int32_t gw_alpha_num;    /* stretch scale a = num/den of GwDistribution<T, num, den>; 0/0 = 2/1 */
+    int32_t gw_alpha_den;
     int32_t reserved;
     uint64_t seed;   /* EnsembleSampler ctor randSeed (sign-extended int), MultiSampler.h:54 */
     uint64_t stream; /* 0 for EnsembleSampler (EnsembleSampler.h:217) */

@@ -1,0 +1,142 @@
+// CPU unit test of the host Chain and its iterators (include/MCMCpp/Chain/*.h): cell layout, block
+// boundaries, saturation of the iterators, burn-in/thinning compaction and the byte budget -- the
+// behaviours the reference documents in MCMCpp/Chain/{Chain,ChainStepIterator,ChainPsetIterator}.h.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "Chain/Chain.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                         \
+    do                                                                      \
+    {                                                                       \
+        if (!(cond))                                                        \
+        {                                                                   \
+            std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond);     \
+            ++failures;                                                     \
+        }                                                                   \
+    } while (0)
+
+typedef MCMC::Chain::Chain<double> ChainD;
+using MCMC::Chain::IncrementStatus;
+
+// value stored for (step, walker, param): distinct everywhere
+static double cell(long s, int w, int p) { return 1000.0 * s + 10.0 * w + p; }
+
+static void fill(ChainD& c, long steps, int W, int D, long first = 0)
+{
+    std::vector<double> row(D);
+    for (long s = 0; s < steps; ++s)
+    {
+        for (int w = 0; w < W; ++w)
+        {
+            for (int p = 0; p < D; ++p) row[p] = cell(first + s, w, p);
+            c.storeWalker(w, row.data());
+        }
+        c.incrementChainStep();
+    }
+}
+
+int main()
+{
+    const int W = 6, D = 3;
+    const unsigned long long stepBytes = sizeof(double) * W * D;
+    {
+        // 5 steps per block, budget 23 steps: blocks of 5,5,5,5,3
+        ChainD c(W, D, 23 * stepBytes, 5 * stepBytes);
+        CHECK(c.getMaxStepCount() == 23);
+        fill(c, 12, W, D);
+        CHECK(c.getStoredStepCount() == 12);
+        // step iterator: contents, ++ across block boundaries, saturation at both ends
+        long s = 0;
+        MCMC::Chain::ChainStepIterator<double> end = c.getStepIteratorEnd();
+        for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != end; ++it, ++s)
+            for (int w = 0; w < W; ++w)
+                for (int p = 0; p < D; ++p) CHECK((*it)[w * D + p] == cell(s, w, p));
+        CHECK(s == 12);
+        MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin();
+        --it;
+        CHECK(it == c.getStepIteratorBegin());
+        it += 7;
+        CHECK((*it)[0] == cell(7, 0, 0));
+        it -= 3;
+        CHECK((*it)[D] == cell(4, 1, 0));
+        it += 1000;
+        CHECK(it == end);
+        ++it;
+        CHECK(it == end);
+        it -= 1000;
+        CHECK(it == c.getStepIteratorBegin());
+        // parameter-set iterator: W*steps sets in order, no phantom cell at block boundaries
+        long k = 0;
+        MCMC::Chain::ChainPsetIterator<double> pend = c.getPsetIteratorEnd();
+        for (MCMC::Chain::ChainPsetIterator<double> pit = c.getPsetIteratorBegin(); pit != pend; ++pit, ++k)
+            for (int p = 0; p < D; ++p) CHECK((*pit)[p] == cell(k / W, (int)(k % W), p));
+        CHECK(k == 12L * W);
+        MCMC::Chain::ChainPsetIterator<double> pit = c.getPsetIteratorEnd();
+        --pit;
+        CHECK((*pit)[D - 1] == cell(11, W - 1, D - 1));
+        // burn 2, keep every 3rd: steps 2, 5, 8, 11
+        c.resetChainForSubSampling(2, 3);
+        CHECK(c.getStoredStepCount() == 4);
+        const long kept[4] = {2, 5, 8, 11};
+        s = 0;
+        for (MCMC::Chain::ChainStepIterator<double> jt = c.getStepIteratorBegin(); jt != c.getStepIteratorEnd(); ++jt, ++s)
+            CHECK((*jt)[W * D - 1] == cell(kept[s], W - 1, D - 1));
+        // special cases of the reference: (0,1) is a no-op, too few steps clears the chain
+        c.resetChainForSubSampling(0, 1);
+        CHECK(c.getStoredStepCount() == 4);
+        c.resetChainForSubSampling(4, 1);
+        CHECK(c.getStoredStepCount() == 0);
+        // the budget: the 23rd step reports EndOfChain, nothing more is stored after it
+        fill(c, 22, W, D);
+        for (int w = 0; w < W; ++w)
+        {
+            double row[3] = {1, 2, 3};
+            c.storeWalker(w, row);
+        }
+        CHECK(c.incrementChainStep() == IncrementStatus::EndOfChain);
+        CHECK(c.getStoredStepCount() == 23 && c.remainingSteps() == 0);
+        CHECK(c.incrementChainStep() == IncrementStatus::EndOfChain);
+        CHECK(c.getStoredStepCount() == 23);
+        c.resetChain();
+        CHECK(c.getStoredStepCount() == 0 && c.remainingSteps() == 23);
+    }
+    {
+        // bulk path used by the device-to-host copies
+        ChainD c(W, D, 11 * stepBytes, 4 * stepBytes);
+        std::int64_t room = 0;
+        double* dst = c.stepsContiguousFrom(&room);
+        CHECK(dst != nullptr && room == 4);
+        for (long s = 0; s < 3; ++s)
+            for (int w = 0; w < W; ++w)
+                for (int p = 0; p < D; ++p) dst[(s * W + w) * D + p] = cell(s, w, p);
+        c.commitSteps(3);
+        dst = c.stepsContiguousFrom(&room);
+        CHECK(room == 1);
+        for (int w = 0; w < W; ++w)
+            for (int p = 0; p < D; ++p) dst[w * D + p] = cell(3, w, p);
+        c.commitSteps(1);
+        dst = c.stepsContiguousFrom(&room);
+        CHECK(room == 4);
+        c.commitSteps(4);
+        dst = c.stepsContiguousFrom(&room);
+        CHECK(room == 3);  // 11-step budget: last block holds 3
+        c.commitSteps(3);
+        dst = c.stepsContiguousFrom(&room);
+        CHECK(dst == nullptr && room == 0);
+        CHECK((*c.getStepIteratorBegin())[5] == cell(0, 1, 2));
+        MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin();
+        it += 3;
+        CHECK((*it)[0] == cell(3, 0, 0));
+    }
+    {
+        // sizes that overflow the reference's 32-bit indexing (ChainBlock.h:116-128): 131072 x 64 walkers
+        MCMC::Chain::Chain<float> big(131072, 64, 3ULL * 131072 * 64 * sizeof(float));
+        CHECK(big.getMaxStepCount() == 3 && big.getCellsPerStep() == 131072LL * 64);
+    }
+    if (failures == 0) std::printf("chain_test OK\n");
+    return failures == 0 ? 0 : 1;
+}

@@ -41,6 +41,9 @@ def ar1_precision(D, rho, t):
 CASES = {
     # name: W, D, calc, params-maker, dtype, steps, slicing, chain steps kept in full
     "iso64x4": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=1000, keep=[1, 2, 10, 1000]),
+    # StretchMove with a non-default stretch scale: GwDistribution<double, 3, 2>
+    "iso64x4_alpha3_2": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=400, keep=[1, 2, 10, 400],
+                             alpha=(3, 2), alpha_code=1),
     "iso100x7": dict(W=100, D=7, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=500, keep=[1, 2, 10, 500]),
     "iso64x4_f32": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F32, steps=1000, keep=[1, 2, 10, 1000]),
     "dense96x16": dict(W=96, D=16, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=300, keep=[1, 2, 10, 300],
@@ -75,7 +78,8 @@ def make(name, c):
         params = np.asarray(c["params"], dtype=t)
     else:
         params = None
-    orc = po.Oracle(W, D, c["calc"], params, seed=0, dtype=dtype)
+    alpha = c.get("alpha", (2, 1))
+    orc = po.Oracle(W, D, c["calc"], params, seed=0, dtype=dtype, alpha=alpha)
     if c.get("skewed_init"):
         pos, logp = po.reference_skewed_initial_values(W, 0.13, 53)
     else:
@@ -83,13 +87,14 @@ def make(name, c):
         logp = orc.logp(pos)
     slicing = c.get("slicing", 1)
     steps = c["steps"]
-    ref = po.reference_run(W, D, c["calc"], params, 0, pos, logp, steps, 1, slicing=slicing, dtype=dtype)
+    ref = po.reference_run(W, D, c["calc"], params, 0, pos, logp, steps, 1, slicing=slicing, dtype=dtype,
+                           alpha_code=c.get("alpha_code", 0))
     assert ref["stored"] == steps + 1 and not ref["chain_full"]
     acc_cum = ref["accepted"].astype(np.int64)
     # reference totals count the initial placement as one accepted step per walker (Walker.h:76,168)
     acc_per_call = np.diff(np.concatenate([[W], acc_cum])).astype(np.uint32)
     out = dict(W=np.int32(W), D=np.int32(D), calc=np.int32(c["calc"]), dtype=np.int32(dtype), seed=np.int64(0),
-               slicing=np.int32(slicing), steps=np.int32(steps),
+               slicing=np.int32(slicing), steps=np.int32(steps), alpha=np.asarray(alpha, dtype=np.int32),
                params=(np.zeros(0, dtype=t) if params is None else params),
                accepted_per_call=acc_per_call, accepted_total=np.uint64(acc_cum[-1]),
                total_steps=np.uint64(ref["total"][-1]))

@@ -9,7 +9,7 @@ from oracle import pyoracle as po
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-SMALL = ["iso64x4", "iso100x7", "iso64x4_f32", "dense96x16", "dense80x5_f32", "rosen80x8", "rosen200x33",
+SMALL = ["iso64x4", "iso64x4_alpha3_2", "iso100x7", "iso64x4_f32", "dense96x16", "dense80x5_f32", "rosen80x8", "rosen200x33",
          "skewed320x2"]
 DIGEST = ["iso600x130", "c2_16384x32", "c3_4096x32"]
 
@@ -27,6 +27,7 @@ class Golden:
         self.calc, self.dtype = int(z["calc"]), int(z["dtype"])
         self.seed, self.slicing, self.steps = int(z["seed"]), int(z["slicing"]), int(z["steps"])
         self.params = z["params"] if z["params"].size else None
+        self.alpha = tuple(int(v) for v in z["alpha"]) if "alpha" in z.files else (2, 1)
         self.accepted_per_call = z["accepted_per_call"]
         self.accepted_total = int(z["accepted_total"])  # includes the W initial placements
         self.total_steps = int(z["total_steps"])

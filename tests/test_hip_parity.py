@@ -51,7 +51,7 @@ def test_device_calculators_bit_exact(calc, D, dtype):
 
 
 def _run_hip_against_golden(g, **kw):
-    s = capi.HipSampler(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype, **kw)
+    s = capi.HipSampler(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype, alpha=g.alpha, **kw)
     s.set_state(g.init_pos, g.init_logp)
     done, acc_calls = 0, []
     for k in sorted(set(g.checked_steps + [g.steps])):

@@ -76,7 +76,7 @@ def test_canonical_conversions():
 
 
 def _run_oracle(g, mode, threads=1):
-    orc = po.Oracle(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype)
+    orc = po.Oracle(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype, alpha=g.alpha)
     np.testing.assert_array_equal(orc.logp(g.init_pos), g.init_logp)
     orc.set_state(g.init_pos, g.init_logp)
     done = 0
