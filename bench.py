@@ -78,6 +78,53 @@ def cpu_baseline(W, D, P, sample_steps):
     return out
 
 
+def bench_split(args, rank, local_rank, world, dist, torch, capi, po):
+    """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling."""
+    from mcmcpp_amd import distributed as md
+    if dist is None:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    W, D = 131072, 64
+    steps_per = 50
+    dev = "cuda:%d" % local_rank
+    ens = md.SplitEnsemble(W, D, lambda b, c: md.HipShardBackend(W, D, capi.CALC_ISO_GAUSSIAN, None, 0, 0, capi.F64, b, c, dev))
+    pos = po.init_positions(po.F64, W, D, salt=0)
+    logp = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank).calc_logp(pos)
+    ens.set_state(pos, logp)
+    for _ in range(args.warmup):
+        ens.run(1, interval=steps_per, save_chain=False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ens.run(1, interval=steps_per, save_chain=False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    _, _, nacc = ens.gather_state()
+    accepted = int(nacc.sum().item())
+    total = float(W) * steps_per * (args.steps + args.warmup)
+    if rank == 0:
+        exchanged = (W // 2) * D * 8 * (world - 1) / world  # bytes each rank receives per half-step
+        print(json.dumps({
+            "metric": "walker-steps/sec + acceptance rate, 131072 walkers x 64 dims split over the GPUs",
+            "value": float(W) * steps_per * args.steps / elapsed, "unit": "walker-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "acceptance_rate": accepted / total,
+            "config": {"workload": "C5: one 131072x64 isotropic-Gaussian ensemble split over %d GPU(s), RCCL all-gather "
+                                   "of the updated half-ensemble slice after every half-step; one step = %d ensemble steps"
+                                   % (world, steps_per), "walkers": W, "dims": D},
+            "allgather": {"bytes_received_per_rank_per_half_step": exchanged,
+                          "half_steps": 2 * steps_per * args.steps}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +137,9 @@ def main():
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
+    ap.add_argument("--mode", default="chains", choices=["chains", "split"],
+                    help="chains (default, the headline): one independent C2 chain per GPU; split: BASELINE config 5, "
+                         "one 131072x64 ensemble split over the GPUs with an RCCL all-gather per half-step")
     ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
                     help="experiments only: the headline workload is the dense (correlated) Gaussian")
     args = ap.parse_args()
@@ -111,6 +161,9 @@ def main():
 
     from mcmcpp_amd import capi
     from oracle import pyoracle as po  # initial positions only (pure integer-hash recipe)
+
+    if args.mode == "split":
+        return bench_split(args, rank, local_rank, world, dist, torch, capi, po)
 
     W, D = args.walkers, args.dims
     assert args.batch % args.interval == 0

@@ -67,6 +67,12 @@ def lib():
         for f in ("so_half_steps_done", "so_near_ties", "so_redraws"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_uint64
+        L.so_half_step_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
+        L.so_half_step_commit.argtypes = [C.c_void_p]
+        L.so_positions_ptr.argtypes = [C.c_void_p]
+        L.so_positions_ptr.restype = C.c_void_p
+        L.so_logp_ptr.argtypes = [C.c_void_p]
+        L.so_logp_ptr.restype = C.c_void_p
         L.so_calc_logp.argtypes = [C.POINTER(_Config), C.c_void_p, C.c_void_p]
         L.so_pcg64_seed.argtypes = [C.POINTER(_Pcg64), C.c_uint64, C.c_uint64]
         L.so_pcg64_seed.restype = None
@@ -173,6 +179,25 @@ class Oracle:
         nacc = np.empty(self.W, dtype=np.uint32)
         assert lib().so_get_state(self.h, _ptr(pos), _ptr(logp), _ptr(nacc)) == 0
         return pos, logp, nacc
+
+    def half_step_shard(self, color, begin, count):
+        a = C.c_uint32(0)
+        rc = lib().so_half_step_shard(self.h, color, begin, count, C.byref(a))
+        if rc:
+            raise ValueError("so_half_step_shard failed: %d" % rc)
+        return a.value
+
+    def half_step_commit(self):
+        assert lib().so_half_step_commit(self.h) == 0
+
+    def positions_view(self):
+        """numpy view (no copy) of the sampler's own [W, D] position array."""
+        buf = (C.c_char * (self.W * self.D * np.dtype(self.np_t).itemsize)).from_address(lib().so_positions_ptr(self.h))
+        return np.frombuffer(buf, dtype=self.np_t).reshape(self.W, self.D)
+
+    def logp_view(self):
+        buf = (C.c_char * (self.W * np.dtype(self.np_t).itemsize)).from_address(lib().so_logp_ptr(self.h))
+        return np.frombuffer(buf, dtype=self.np_t)
 
     @property
     def near_ties(self):

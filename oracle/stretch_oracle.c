@@ -267,6 +267,27 @@ int so_run(so_sampler* s, int64_t n_saved, int32_t interval, void* chain_out,
     return run_f32(s, n_saved, interval, (float*)chain_out, accepted_per_step, mode, threads);
 }
 
+int so_half_step_shard(so_sampler* s, int32_t color, int32_t begin, int32_t count, uint32_t* accepted)
+{
+    if (!s || (color != 0 && color != 1)) return -1;
+    if ((int)(s->half_steps & 1) != color) return -2; /* red, black, red, ... */
+    if (begin < 0 || count < 0 || begin + count > s->cfg.num_walkers / 2) return -3;
+    uint32_t a = s->cfg.dtype == SO_F64 ? half_step_shard_f64(s, color, begin, count)
+                                        : half_step_shard_f32(s, color, begin, count);
+    if (accepted) *accepted = a;
+    return 0;
+}
+
+int so_half_step_commit(so_sampler* s)
+{
+    if (!s) return -1;
+    s->half_steps += 1;
+    return 0;
+}
+
+void* so_positions_ptr(so_sampler* s) { return s ? s->pos : NULL; }
+void* so_logp_ptr(so_sampler* s) { return s ? s->logp : NULL; }
+
 int so_get_state(so_sampler* s, void* positions, void* logp, uint32_t* n_accept)
 {
     if (!s) return -1;

@@ -78,6 +78,16 @@ int so_set_state(so_sampler* s, const void* positions, const void* logp);
 int so_run(so_sampler* s, int64_t n_saved, int32_t interval, void* chain_out,
            uint32_t* accepted_per_step, int32_t mode, int32_t threads);
 
+/* One half-step (color 0 = red, 1 = black) restricted to walkers [begin, begin+count) of that colour,
+ * counter-addressed draws; after every shard of the colour has been stepped (by this sampler or by
+ * replicas that exchange the updated rows) call so_half_step_commit once to advance the stream.
+ * Used by the CPU tests of the multi-GPU driver. */
+int so_half_step_shard(so_sampler* s, int32_t color, int32_t begin, int32_t count, uint32_t* accepted);
+int so_half_step_commit(so_sampler* s);
+/* the sampler's own position / log-posterior arrays (W*D and W elements), for zero-copy views */
+void* so_positions_ptr(so_sampler* s);
+void* so_logp_ptr(so_sampler* s);
+
 /* any pointer may be NULL */
 int so_get_state(so_sampler* s, void* positions, void* logp, uint32_t* n_accept);
 
