@@ -82,8 +82,15 @@ typedef struct mcmcpp_hip_config {
     int32_t gw_alpha_den;
     void* device_positions;  /* optional caller-owned DEVICE buffer of W*D elements used in place of an
                                 internal one (e.g. memory registered with a collective library) */
-    void* hip_stream;        /* optional hipStream_t to launch on; NULL = a stream owned by the handle */
+    void* hip_stream;        /* hipStream_t to launch on when MCMCPP_HIP_FLAG_CALLER_STREAM is set (NULL is then the
+                                legacy default stream); otherwise ignored and the handle owns a private stream */
+    uint32_t flags;          /* MCMCPP_HIP_FLAG_* */
+    uint32_t reserved;
 } mcmcpp_hip_config;
+
+/* launch every kernel and copy on the caller's stream (config.hip_stream), so that the caller's own work on
+ * that stream -- e.g. RCCL collectives issued through torch.distributed -- is ordered with the half-steps */
+#define MCMCPP_HIP_FLAG_CALLER_STREAM 1u
 
 /* EnsembleSampler::EnsembleSampler / ~EnsembleSampler */
 int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out);

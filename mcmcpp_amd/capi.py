@@ -28,7 +28,10 @@ class Config(C.Structure):
                 ("calc_params", C.c_void_p), ("seed", C.c_uint64), ("stream", C.c_uint64), ("device", C.c_int32),
                 ("shard_begin", C.c_int32), ("shard_count", C.c_int32), ("graph_steps", C.c_int32),
                 ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32),
-                ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p)]
+                ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p), ("flags", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+FLAG_CALLER_STREAM = 1
 
 
 def library_path():
@@ -104,7 +107,8 @@ class HipSampler:
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self.cfg = Config(C.sizeof(Config), dtype, W, D, calc_id, 0 if self.params is None else self.params.size,
                           _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
-                          shard_count, graph_steps, alpha[0], alpha[1], device_positions, hip_stream)
+                          shard_count, graph_steps, alpha[0], alpha[1], device_positions,
+                          0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, 0)
         self.h = C.c_void_p()
         rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
         if rc != OK:

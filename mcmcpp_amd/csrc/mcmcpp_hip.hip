@@ -195,9 +195,9 @@ public:
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;
 
-        if (c.hip_stream)
+        if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
         {
-            stream = (hipStream_t)c.hip_stream;
+            stream = (hipStream_t)c.hip_stream;  // may be the null (legacy default) stream
             own_stream = false;
         }
         else

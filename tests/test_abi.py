@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(lib):
 
 def test_config_struct_matches_header(lib):
     # struct_size is checked by the library: a python/C layout mismatch would be rejected here
-    cfg = capi.Config(C.sizeof(capi.Config) - 4, 0, 64, 4, 0, 0, None, 0, 0, -1, 0, 0, 0, 0, 0, None, None)
+    cfg = capi.Config(C.sizeof(capi.Config) - 4, 0, 64, 4, 0, 0, None, 0, 0, -1, 0, 0, 0, 0, 0, None, None, 0, 0)
     h = C.c_void_p()
     assert lib.mcmcpp_hip_create(C.byref(cfg), C.byref(h)) == 1
     assert b"struct_size" in lib.mcmcpp_hip_last_error(None)
