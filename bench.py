@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--dims", type=int, default=32)
     ap.add_argument("--cpu-sample-steps", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-chain", action="store_true", help="experiments only: store nothing")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
     ap.add_argument("--mode", default="chains", choices=["chains", "split"],
                     help="chains (default, the headline): one independent C2 chain per GPU; split: BASELINE config 5, "
@@ -176,7 +177,7 @@ def main():
     sampler.set_state(pos, sampler.calc_logp(pos))
 
     def bench_step():
-        return sampler.run(n_saved, interval=args.interval, save_chain=True, want_accepted=not args.no_accepted)
+        return sampler.run(n_saved, interval=args.interval, save_chain=not args.no_chain, want_accepted=not args.no_accepted)
 
     for _ in range(args.warmup):
         bench_step()

@@ -156,8 +156,8 @@ def test_resume_reset_and_unsaved_runs_are_seamless():
 def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
     base = None
     for env in [{}, {"MCMCPP_HIP_PASSES": "1"}, {"MCMCPP_HIP_PASSES": "4"}, {"MCMCPP_HIP_PASSES": "16"},
-                {"MCMCPP_HIP_CHAIN_CHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"}]:
-        for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_CHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS"):
+                {"MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"}]:
+        for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -4,7 +4,7 @@ p() { python - "$1" "$2" <<'PY'
 import json,sys
 l=[x for x in open(sys.argv[2]) if x.startswith("{")]
 if not l: print(sys.argv[1], "FAILED"); sys.exit(0)
-d=json.loads(l[-1]); print("%-28s %.3e w-s/s  %.2f us/launch  frac %.3f  acc %.4f" % (sys.argv[1], d["value"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["acceptance_rate"]))
+d=json.loads(l[-1]); print("%-28s %.3e w-s/s  %.2f ms/step  %.2f us/launch  frac %.3f  acc %.4f" % (sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline"]["frac"], d["acceptance_rate"]))
 PY
 }
 B="python bench.py --steps 4 --warmup 1 --no-cpu-baseline"
