@@ -216,6 +216,12 @@ def main():
         bytes_per_launch = (W // 2) * (bytes_per_update + saved_fraction * D * 8)
         us_per_launch = gpu_ms * 1e3 / launches
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+        # HBM bytes per launch from the PMC counters: collected by a separate rocprofv3 --pmc run of this very
+        # command (counters cannot be read from inside the process) and committed with its provenance
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if args.calc == "dense" and (W, D) == (16384, 32) and os.path.exists(pmc_path):
+            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
         line = {
             "metric": "walker-steps/sec + acceptance rate, 16384 walkers x 32 dims, 1/2/4/8 GPU",
             "value": walker_steps / elapsed,
@@ -238,10 +244,12 @@ def main():
                        "walkers": W, "dims": D, "ensemble_steps_per_step": args.batch,
                        "slicing_interval": args.interval, "chains": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "stretch_half_step_kernel<double, DenseGaussianFn, EPL=2, LPW=16>",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": us_per_launch,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                           "passes; FETCH_SIZE doubled per the gfx950 correction)" if traffic else None,
                          "note": "avg launch duration = HIP-event time on the launch stream over the graph-replayed "
                                  "half-step launches / launches; it includes the ~1.5 us dependent-launch boundary"},
         }

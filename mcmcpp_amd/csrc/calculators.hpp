@@ -109,7 +109,11 @@ struct IsoGaussianFn
 {
     static constexpr bool kNeedsStage = false;
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
-    __device__ static void block_init(T*, const T*, int, bool, int, int) {}
+    struct Prefetch
+    {
+    };
+    __device__ __forceinline__ static void block_prefetch(Prefetch&, const T*, int, bool, int, int) {}
+    __device__ __forceinline__ static void block_commit(const Prefetch&, T*, const T*, int, bool, int, int) {}
     template <int EPL, int LPW>
     struct Regs
     {
@@ -130,109 +134,136 @@ struct IsoGaussianFn
 };
 
 // -1/2 x^T P x, params = P transposed (PT[j*D + i] = P[i][j]) so that a group's lanes read contiguously.
-// The matrix is read D times per walker, so each workgroup keeps a copy in LDS (when it fits); the
-// proposal is published to wave-private LDS so that every lane can read every x_j (broadcast reads).
-// y_i = sum_j P_ij x_j is accumulated as one fma chain in ascending j, as the host Calculator does.
+// The matrix is read once per walker, so each workgroup keeps a copy in LDS: zero-padded to N2 x N2
+// (N2 = the walker's padded dimension, a power of two) when N2 <= 64, which lets the product loop run
+// without any bounds test; the proposal is published to wave-private LDS so that every lane can read every
+// x_j with broadcast reads.  y_i = sum_j P_ij x_j is accumulated as one fma chain in ascending j, as the host
+// Calculator does (padding contributes fma(0, 0, acc), which leaves acc untouched bit for bit: a chain that
+// starts at +0 never sits at -0 under round-to-nearest).
 template <class T>
 struct DenseGaussianFn
 {
     static constexpr bool kNeedsStage = true;
+    static constexpr int kMaxPadded = 64;
+
+    __host__ __device__ static int padded_dim(int D)
+    {
+        int n2 = Vec16<T>::N;
+        while (n2 < D) n2 <<= 1;
+        return n2;
+    }
     __host__ __device__ static size_t block_scratch_elems(int D)
     {
-        const size_t e = (size_t)D * (size_t)D;
-        return e * sizeof(T) <= kMaxBlockScratchBytes ? e : 0;
-    }
-    __device__ static void block_init(T* scratch, const T* pt, int D, bool vec_ok, int tid, int nthreads)
-    {
-        if (block_scratch_elems(D) == 0) return;
-        constexpr int VN = Vec16<T>::N;
-        typedef typename Vec16<T>::type V;
-        const int total = D * D;
-        if (vec_ok)
-            for (int k = tid * VN; k < total; k += nthreads * VN)
-                *reinterpret_cast<V*>(scratch + k) = *reinterpret_cast<const V*>(pt + k);
-        else
-            for (int k = tid; k < total; k += nthreads) scratch[k] = pt[k];
+        const int n2 = padded_dim(D);
+        return n2 <= kMaxPadded ? (size_t)n2 * (size_t)n2 : 0;
     }
 
-    // Walkers of up to 32 padded dimensions keep their lane's slice of the matrix in registers (loaded once
-    // per wavefront, before the random draws are known); larger ones read it from the LDS / global copy.
+    // The workgroup's LDS copy is filled in two steps so that the global loads are issued with the launch's
+    // first batch of loads and land in registers while other work proceeds: every thread prefetches up to
+    // kPrefetchVecs 16-byte pieces, commit stores them (and any remainder) to LDS.
+    static constexpr int kPrefetchVecs = 2;
+    struct Prefetch
+    {
+        typename Vec16<T>::type v[kPrefetchVecs];
+    };
+    // piece k of the padded matrix (16 bytes = VN cells of row j starting at column i)
+    __device__ __forceinline__ static typename Vec16<T>::type fetch_piece(const T* pt, int D, int n2, bool vec_ok, int k)
+    {
+        constexpr int VN = Vec16<T>::N;
+        typedef typename Vec16<T>::type V;
+        const int cell = k * VN;
+        const int j = cell / n2, i = cell - j * n2;
+        V out;
+        T* o = reinterpret_cast<T*>(&out);
+        if (vec_ok)
+        {
+            // D is a multiple of VN: a piece lies wholly inside or wholly outside the matrix
+            const bool inside = j < D && i < D;
+            const V c = *reinterpret_cast<const V*>(pt + (size_t)(inside ? j : 0) * D + (inside ? i : 0));
+            const T* cs = reinterpret_cast<const T*>(&c);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = inside ? cs[e] : (T)0;
+        }
+        else
+        {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) o[e] = (j < D && i + e < D) ? pt[(size_t)j * D + i + e] : (T)0;
+        }
+        return out;
+    }
+    __device__ __forceinline__ static void block_prefetch(Prefetch& pf, const T* pt, int D, bool vec_ok, int tid, int nthreads)
+    {
+        const int n2 = padded_dim(D);
+        if (n2 > kMaxPadded) return;
+        const int pieces = n2 * n2 / Vec16<T>::N;
+#pragma unroll
+        for (int r = 0; r < kPrefetchVecs; ++r)
+        {
+            const int k = tid + r * nthreads;
+            if (k < pieces) pf.v[r] = fetch_piece(pt, D, n2, vec_ok, k);
+        }
+    }
+    __device__ __forceinline__ static void block_commit(const Prefetch& pf, T* scratch, const T* pt, int D, bool vec_ok, int tid,
+                                                        int nthreads)
+    {
+        typedef typename Vec16<T>::type V;
+        const int n2 = padded_dim(D);
+        if (n2 > kMaxPadded) return;
+        const int pieces = n2 * n2 / Vec16<T>::N;
+        V* dst = reinterpret_cast<V*>(scratch);
+#pragma unroll
+        for (int r = 0; r < kPrefetchVecs; ++r)
+        {
+            const int k = tid + r * nthreads;
+            if (k < pieces) dst[k] = pf.v[r];
+        }
+        for (int k = tid + kPrefetchVecs * nthreads; k < pieces; k += nthreads) dst[k] = fetch_piece(pt, D, n2, vec_ok, k);
+    }
+
     template <int EPL, int LPW>
     struct Regs
     {
-        static constexpr bool kUse = (EPL * LPW <= 32);
-        T col[kUse ? EPL * LPW : 1][EPL];
     };
     template <int EPL, int LPW>
-    __device__ __forceinline__ static void preload(const GroupCtx<T, EPL, LPW>& g, const T* pt_global, Regs<EPL, LPW>& r)
+    __device__ __forceinline__ static void preload(const GroupCtx<T, EPL, LPW>&, const T*, Regs<EPL, LPW>&)
     {
-        if constexpr (Regs<EPL, LPW>::kUse)
-        {
-            // called after block_init + barrier: the workgroup's LDS copy of the matrix is the source
-            if (g.block_scratch != nullptr)
-                preload_from<EPL, LPW>(g, g.block_scratch, r);
-            else
-                preload_from<EPL, LPW>(g, pt_global, r);
-        }
-    }
-    template <int EPL, int LPW, class PtrT>
-    __device__ __forceinline__ static void preload_from(const GroupCtx<T, EPL, LPW>& g, PtrT pt, Regs<EPL, LPW>& r)
-    {
-        {
-            constexpr int N2 = EPL * LPW;
-            constexpr int VN = Vec16<T>::N;
-            typedef typename Vec16<T>::type V;
-            const int D = g.dims;
-            const int i0 = g.first_index();
-            // branch-free: every load is issued unconditionally from a clamped (always valid) address and the
-            // cells outside the D x D matrix are zeroed afterwards, so all N2 loads are in flight together
-            if (g.vec_ok)
-            {
-#pragma unroll
-                for (int j = 0; j < N2; ++j)
-                {
-                    const int jc = j < D ? j : D - 1;
-#pragma unroll
-                    for (int v = 0; v < EPL / VN; ++v)
-                    {
-                        const int ic = (i0 + v * VN < D) ? i0 + v * VN : D - VN;
-                        const V c = *reinterpret_cast<const V*>(pt + (size_t)jc * D + ic);
-                        const T* cs = reinterpret_cast<const T*>(&c);
-                        const bool inside = (j < D) && (i0 + v * VN < D);
-#pragma unroll
-                        for (int k = 0; k < VN; ++k) r.col[j][v * VN + k] = inside ? cs[k] : (T)0;
-                    }
-                }
-            }
-            else
-            {
-#pragma unroll
-                for (int j = 0; j < N2; ++j)
-                {
-                    const int jc = j < D ? j : D - 1;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e)
-                    {
-                        const int ic = (i0 + e < D) ? i0 + e : D - 1;
-                        const T c = pt[(size_t)jc * D + ic];
-                        r.col[j][e] = ((j < D) && (i0 + e < D)) ? c : (T)0;
-                    }
-                }
-            }
-        }
     }
 
-    template <int EPL, int LPW, class PtrT>
-    __device__ __forceinline__ static void mat_vec(const GroupCtx<T, EPL, LPW>& g, PtrT pt, T (&acc)[EPL])
+    // matrix in global memory (D x D, row stride D): the fallback for padded dimensions above kMaxPadded
+    template <int EPL, int LPW>
+    __device__ __forceinline__ static void mat_vec_global(const GroupCtx<T, EPL, LPW>& g, const T* pt, T (&acc)[EPL])
     {
-        constexpr int VN = Vec16<T>::N;
-        typedef typename Vec16<T>::type V;
         const int D = g.dims;
         const int i0 = g.first_index();
         const T* xs = g.stage + (g.lane - g.sub) * EPL;
-        if (g.vec_ok)
+        for (int j = 0; j < D; ++j)
         {
-            for (int j = 0; j < D; j += VN)
+            const T xj = xs[j];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (i0 + e < D) acc[e] = __builtin_fma(pt[(size_t)j * D + i0 + e], xj, acc[e]);
+        }
+    }
+
+    template <int EPL, int LPW>
+    __device__ __forceinline__ static T eval(const GroupCtx<T, EPL, LPW>& g, const T* pt_global, const Regs<EPL, LPW>&,
+                                             const T (&x)[EPL])
+    {
+        constexpr int N2 = EPL * LPW;
+        constexpr int VN = Vec16<T>::N;
+        typedef typename Vec16<T>::type V;
+        g.publish(x);
+        T acc[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc[e] = (T)0;
+        if constexpr (N2 <= kMaxPadded)
+        {
+            // no bounds tests; unrolled four x-vectors at a time so that a bounded number of LDS reads is in
+            // flight (a full unroll makes the compiler hold the whole matrix slice in registers)
+            const T* xs = g.stage + (g.lane - g.sub) * EPL;
+            const T* pt = g.block_scratch + g.first_index();
+#pragma unroll 4
+            for (int j = 0; j < N2; j += VN)
             {
                 const V xv = *reinterpret_cast<const V*>(xs + j);
                 const T* xj = reinterpret_cast<const T*>(&xv);
@@ -242,67 +273,16 @@ struct DenseGaussianFn
 #pragma unroll
                     for (int v = 0; v < EPL / VN; ++v)
                     {
-                        if (i0 + v * VN < D)
-                        {
-                            const V c = *reinterpret_cast<const V*>(pt + (size_t)(j + jj) * D + i0 + v * VN);
-                            const T* cs = reinterpret_cast<const T*>(&c);
+                        const V c = *reinterpret_cast<const V*>(pt + (j + jj) * N2 + v * VN);
+                        const T* cs = reinterpret_cast<const T*>(&c);
 #pragma unroll
-                            for (int k = 0; k < VN; ++k)
-                                acc[v * VN + k] = __builtin_fma(cs[k], xj[jj], acc[v * VN + k]);
-                        }
+                        for (int k = 0; k < VN; ++k) acc[v * VN + k] = __builtin_fma(cs[k], xj[jj], acc[v * VN + k]);
                     }
                 }
             }
         }
         else
-        {
-            for (int j = 0; j < D; ++j)
-            {
-                const T xj = xs[j];
-#pragma unroll
-                for (int e = 0; e < EPL; ++e)
-                    if (i0 + e < D) acc[e] = __builtin_fma(pt[(size_t)j * D + i0 + e], xj, acc[e]);
-            }
-        }
-    }
-
-    template <int EPL, int LPW>
-    __device__ __forceinline__ static T eval(const GroupCtx<T, EPL, LPW>& g, const T* pt_global, const Regs<EPL, LPW>& r,
-                                             const T (&x)[EPL])
-    {
-        g.publish(x);
-        T acc[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) acc[e] = (T)0;
-        if constexpr (Regs<EPL, LPW>::kUse)
-        {
-            constexpr int N2 = EPL * LPW;
-            constexpr int VN = Vec16<T>::N;
-            typedef typename Vec16<T>::type V;
-            // the whole proposal of this walker, read back from the stage with broadcast 16-byte reads
-            T xs[N2];
-            const T* src = g.stage + (g.lane - g.sub) * EPL;
-#pragma unroll
-            for (int j = 0; j < N2; j += VN)
-            {
-                const V xv = *reinterpret_cast<const V*>(src + j);
-                const T* xp = reinterpret_cast<const T*>(&xv);
-#pragma unroll
-                for (int k = 0; k < VN; ++k) xs[j + k] = xp[k];
-            }
-            // No guards: cells outside the matrix hold col = 0 and x = +0, and an fma chain that starts at +0
-            // can never sit at -0 under round-to-nearest, so fma(0, 0, acc) == acc bit for bit.
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-            {
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) acc[e] = __builtin_fma(r.col[j][e], xs[j], acc[e]);
-            }
-        }
-        else if (g.block_scratch != nullptr)
-            mat_vec<EPL, LPW>(g, g.block_scratch, acc);
-        else
-            mat_vec<EPL, LPW>(g, pt_global, acc);
+            mat_vec_global<EPL, LPW>(g, pt_global, acc);
         const int i0 = g.first_index();
         T t[EPL];
 #pragma unroll
@@ -317,7 +297,11 @@ struct RosenbrockFn
 {
     static constexpr bool kNeedsStage = false;
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
-    __device__ static void block_init(T*, const T*, int, bool, int, int) {}
+    struct Prefetch
+    {
+    };
+    __device__ __forceinline__ static void block_prefetch(Prefetch&, const T*, int, bool, int, int) {}
+    __device__ __forceinline__ static void block_commit(const Prefetch&, T*, const T*, int, bool, int, int) {}
     template <int EPL, int LPW>
     struct Regs
     {
@@ -359,7 +343,11 @@ struct SkewedGaussian2DFn
 {
     static constexpr bool kNeedsStage = false;
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
-    __device__ static void block_init(T*, const T*, int, bool, int, int) {}
+    struct Prefetch
+    {
+    };
+    __device__ __forceinline__ static void block_prefetch(Prefetch&, const T*, int, bool, int, int) {}
+    __device__ __forceinline__ static void block_commit(const Prefetch&, T*, const T*, int, bool, int, int) {}
     template <int EPL, int LPW>
     struct Regs
     {

@@ -23,6 +23,8 @@ struct LaunchTable
     CalcFn calc[kLpwLevels][kMaxEplShift];
 };
 
+void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, hipStream_t stream);
+void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, hipStream_t stream);
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream);
 

@@ -85,6 +85,16 @@ const LaunchTable<float>* table_for<float>(int calc_id)
 
 namespace mcmcpp
 {
+void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
+    hipLaunchKernelGGL(fill_draws_kernel<double>, dim3(grid), dim3(256), 0, stream, a, base);
+}
+void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
+    hipLaunchKernelGGL(fill_draws_kernel<float>, dim3(grid), dim3(256), 0, stream, a, base);
+}
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream)
 {
@@ -228,6 +238,8 @@ public:
         HIP_TRY(hipMalloc(&d_ctl, sizeof(StepCtl) * 2));
         HIP_TRY(hipMalloc(&d_run, sizeof(RunInfo)));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
+        HIP_TRY(hipMalloc(&d_draws, sizeof(DrawRec<T>) * (size_t)W));
+        HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W));
 #ifdef MCMCPP_STAMPS
         HIP_TRY(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d_stamps, 0, 8 * sizeof(unsigned long long)));
@@ -577,6 +589,7 @@ private:
         a.jump_hi = d_jump_hi;
         a.task_jump = d_task_jump;
         a.calc_params = d_params;
+        a.draws = d_draws;
         a.half_jump = half_jump;
         for (int k = 0; k < 3; ++k) a.draw_jump[k] = pcg_jump(inc, (unsigned)k + 1);
         a.inc = inc;
@@ -612,12 +625,18 @@ private:
         StepCtl* c = (StepCtl*)((char*)h_pinned + 128);
         const Affine128 j = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps);
         c->state = apply(j, state0);
+        const U128 state1 = apply(half_jump, c->state);
+        c->state2 = apply(half_jump, state1);
         c->half_step = half_steps;
         c->step_in_run = step_in_run;
         c->chain_slot = 0;
         c->save_phase = 0;
         c->partial_slot = 0;
         HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
+        // the draw records of the next red and the next black half-step (afterwards the launches keep them going)
+        launch_fill_draws(make_args(0), c->state, stream);
+        launch_fill_draws(make_args(1), state1, stream);
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MCMCPP_HIP_OK;
     }
@@ -628,12 +647,13 @@ private:
         half_fn(args_blk, grid_blocks(), stream);
     }
 
-    int ensure_graphs()
+    // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
+    // graph_steps for the bulk, one graph per distinct remainder)
+    int graph_for(int steps, hipGraphExec_t* out)
     {
-        if (graph_steps < 1 || exec_many) return MCMCPP_HIP_OK;
-        for (int which = 0; which < 2; ++which)
+        if ((int)graph_cache.size() <= steps) graph_cache.resize((size_t)steps + 1, nullptr);
+        if (!graph_cache[steps])
         {
-            const int steps = which == 0 ? graph_steps : 1;
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
             for (int s = 0; s < steps; ++s) enqueue_step();
@@ -642,9 +662,17 @@ private:
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
             HIP_TRY(hipGraphDestroy(g));
-            (which == 0 ? exec_many : exec_one) = ex;
+            graph_cache[steps] = ex;
         }
+        *out = graph_cache[steps];
         return MCMCPP_HIP_OK;
+    }
+
+    int ensure_graphs()
+    {
+        if (graph_steps < 1) return MCMCPP_HIP_OK;
+        hipGraphExec_t ex;
+        return graph_for(graph_steps, &ex);
     }
 
     // enqueue `steps` ensemble steps on the launch stream (graph replays, or plain launches when graphs are off)
@@ -653,15 +681,18 @@ private:
         int64_t left = steps;
         if (graph_steps >= 1)
         {
-            while (left >= graph_steps)
+            hipGraphExec_t ex = nullptr;
+            if (left >= graph_steps)
             {
-                HIP_TRY(hipGraphLaunch(exec_many, stream));
-                left -= graph_steps;
+                int rc = graph_for(graph_steps, &ex);
+                if (rc) return rc;
+                for (; left >= graph_steps; left -= graph_steps) HIP_TRY(hipGraphLaunch(ex, stream));
             }
-            while (left > 0)
+            if (left > 0)
             {
-                HIP_TRY(hipGraphLaunch(exec_one, stream));
-                --left;
+                int rc = graph_for((int)left, &ex);  // one replay for the remainder
+                if (rc) return rc;
+                HIP_TRY(hipGraphLaunch(ex, stream));
             }
         }
         else
@@ -719,14 +750,15 @@ private:
     void release()
     {
         if (device >= 0) hipSetDevice(device);
-        if (exec_many) hipGraphExecDestroy(exec_many);
-        if (exec_one) hipGraphExecDestroy(exec_one);
+        for (hipGraphExec_t ex : graph_cache)
+            if (ex) hipGraphExecDestroy(ex);
         if (own_pos && d_pos) hipFree(d_pos);
         if (d_logp) hipFree(d_logp);
         if (d_nacc) hipFree(d_nacc);
         if (d_ctl) hipFree(d_ctl);
         if (d_run) hipFree(d_run);
         if (d_diag) hipFree(d_diag);
+        if (d_draws) hipFree(d_draws);
         if (d_partials) hipFree(d_partials);
         if (d_acc) hipFree(d_acc);
         for (int k = 0; k < 2; ++k)
@@ -767,6 +799,7 @@ private:
     StepCtl* d_ctl = nullptr;
     RunInfo* d_run = nullptr;
     Diag* d_diag = nullptr;
+    DrawRec<T>* d_draws = nullptr;
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     uint32_t* d_partials = nullptr;
     int partial_slots = 1, partial_waves = 0;
@@ -775,7 +808,7 @@ private:
     U128 state0, inc;
     Affine128 half_jump;
     HalfStepArgs<T> args_red, args_blk;
-    hipGraphExec_t exec_many = nullptr, exec_one = nullptr;
+    std::vector<hipGraphExec_t> graph_cache;  // [steps] -> instantiated graph
     uint64_t half_steps = 0, steps_since_reset = 0;
     double last_ms = 0.0;
     int64_t last_launches = 0;

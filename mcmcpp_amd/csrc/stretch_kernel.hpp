@@ -10,11 +10,13 @@
 // base EPL), so a wavefront reads and writes whole walker rows with fully coalesced 16-byte accesses
 // (walker-major, parameter-contiguous rows, as the reference lays them out).  A wavefront owns
 // NW = (64/LPW)*passes consecutive walkers:
-//   phase A (one walker per lane, lanes 0..NW-1): jump the pcg64 stream to the walker's three draws,
-//            partner index, stretch factor z, (D-1) ln z, ln U, current log-posterior -> wave-private LDS
-//   phase B (LPW lanes per walker, `passes` rounds of 64/LPW walkers): gather the partner row, form the
-//            proposal, evaluate the Calculator functor (cross-lane tree reduction), Metropolis accept
-//            in place, optional chain store, per-step accepted count
+//   update   (LPW lanes per walker, `passes` rounds of 64/LPW walkers): read the walker's draw record,
+//            gather the partner row, form the proposal, evaluate the Calculator functor (cross-lane tree
+//            reduction), Metropolis accept in place, optional chain store, per-step accepted count
+//   draws    (one lane per draw): the random draws do not depend on the walkers, so the three draws each of
+//            these walkers needs at its NEXT update (two half-steps ahead: same colour, same wavefront) are
+//            computed now, in the shadow of the partner-row gather, and left in a 32-byte record per walker.
+//            The launch's dependent chain is then two memory round trips plus the calculator.
 // No MFMA: the work is element-wise plus a per-walker reduction.
 #pragma once
 
@@ -34,6 +36,7 @@ namespace mcmcpp
 struct StepCtl
 {
     U128 state;            // engine state before the first draw of this half-step
+    U128 state2;           // the same two half-steps later (the next update of this colour)
     uint64_t half_step;    // half-steps executed since set_state
     uint64_t step_in_run;  // ensemble step index inside the current run() call
     long long chain_slot;  // stored steps written so far in this run (slot of the next one)
@@ -48,6 +51,17 @@ struct RunInfo
     uint32_t* accepted_per_step; // device counters [steps of this run] or nullptr
     int64_t interval;            // store the last step of every `interval`
     int64_t chain_slot_base;     // slot of the first stored step of this run
+};
+
+// The random part of one stretch-move update, computed one update ahead (StretchMove.h:102,104,110,113).
+template <class T>
+struct alignas(16) DrawRec
+{
+    T z;               // stretch factor
+    T zs;              // (D-1) ln z
+    T ln_u;            // ln U of the accept test
+    uint32_t partner;  // index inside the complementary half
+    uint32_t pad_;
 };
 
 struct Diag
@@ -70,6 +84,7 @@ struct HalfStepArgs
     const Affine128* jump_hi; // [ceil(n/256)] map of 3*256*m draws
     const Affine128* task_jump; // [3n] map of t+1 draws (base state -> state behind draw t), or nullptr for large n
     const T* calc_params;
+    DrawRec<T>* draws;        // [2][n] records of the next update of every walker (colour-major)
     Affine128 half_jump;      // map of 3*n draws: this half-step's base state -> the next one's
     Affine128 draw_jump[3];   // maps of 1, 2, 3 draws: a walker's base state -> the state behind draw k
     U128 inc;                 // pcg stream increment
@@ -156,28 +171,23 @@ __device__ __forceinline__ float dev_log(float x) { return logf(x); }
 __device__ __forceinline__ double dev_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float dev_abs(float x) { return fabsf(x); }
 
-// wave-private LDS record of phase A
-template <class T>
-struct PhaseA
-{
-    T z[64];
-    T zs[64];
-    T ln_u[64];
-    uint32_t partner[64];
-};
-
 constexpr int kWavesPerBlock = 4;
 
 // Diagnostic build only (make STAMPS=1 -> libmcmcpp_hip_stamps.so): wavefront 0 of workgroup 0 drains its
 // memory counters and records the shader clock at a few points; the product build compiles none of it.
 #ifdef MCMCPP_STAMPS
+#ifdef MCMCPP_STAMPS_DRAIN  // attribute waits to the segment that issued the memory operations
+#define MCMCPP_STAMP_DRAIN "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+#else  // leave the kernel's own overlap intact: only read the clock
+#define MCMCPP_STAMP_DRAIN ""
+#endif
 #define MCMCPP_STAMP(k)                                                                     \
     do                                                                                      \
     {                                                                                       \
         if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x < 64)                     \
         {                                                                                   \
             unsigned long long t_;                                                          \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            asm volatile(MCMCPP_STAMP_DRAIN "s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
             if (threadIdx.x == 0) stamp_val[k] = t_;                                        \
         }                                                                                   \
     } while (0)
@@ -188,29 +198,97 @@ constexpr int kWavesPerBlock = 4;
     } while (0)
 #endif
 
-// dynamic LDS of one workgroup: [phase-A records][proposal stage (if the calculator wants it)][calculator tables]
+// dynamic LDS of one workgroup: [proposal stage (if the calculator wants it)][calculator tables]
 template <class T, class Calc, int EPL>
 struct LdsLayout
 {
-    __host__ __device__ static constexpr size_t stage_offset() { return kWavesPerBlock * sizeof(PhaseA<T>); }
+    __host__ __device__ static constexpr size_t stage_offset() { return 0; }
     __host__ __device__ static constexpr size_t block_offset()
     {
         return stage_offset() + (Calc::kNeedsStage ? (size_t)kWavesPerBlock * 64 * EPL * sizeof(T) : 0);
     }
     __host__ static size_t bytes(int dims) { return block_offset() + Calc::block_scratch_elems(dims) * sizeof(T); }
 };
-static_assert(sizeof(PhaseA<double>) % 16 == 0 && sizeof(PhaseA<float>) % 16 == 0, "LDS pieces must stay 16-byte aligned");
+
+// One random draw of one walker: task k of the walker at position i of the half (draw 3*i + k of the
+// half-step whose base engine state is `base`), written into the walker's record.  k = 0: partner =
+// engine(n) (StretchMove.h:102); k = 1: z = Gw(u) and (D-1) ln z (StretchMove.h:104,110); k = 2:
+// ln U = -(-log(1-u)/1) (StretchMove.h:113).  One lane per draw keeps the dependent chain short.
+template <class T>
+__device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base, const Affine128& jump_a,
+                                             const Affine128& jump_b, bool direct, int k, DrawRec<T>* rec)
+{
+    U128 s;
+    if (direct)
+        s = apply(jump_a, base);
+    else
+    {
+        s = apply(jump_b, apply(jump_a, base));
+        const Affine128 dj = k == 0 ? a.draw_jump[0] : (k == 1 ? a.draw_jump[1] : a.draw_jump[2]);
+        s = apply(dj, s);
+    }
+    const uint64_t r = pcg_output(s);
+    if (k == 0)
+    {
+        if (r < a.redraw_threshold) atomicAdd(&a.diag->redraws, 1ULL);
+        rec->partner = a.n_is_pow2 ? (uint32_t)(r & (uint64_t)(a.n - 1)) : (uint32_t)(r % (uint64_t)a.n);
+    }
+    else
+    {
+        const T u = canonical(r, T());
+        const T tmp = a.gw_term1 * u + a.gw_inv_sqrt;
+        const T z = tmp * tmp;                 // GwDistribution.h:58
+        const T arg = (k == 1) ? z : (T)1 - u;  // one logarithm serves both kinds of lane
+        const T lg = dev_log(arg);
+        if (k == 1)
+        {
+            rec->z = z;
+            rec->zs = lg * a.dims_minus_one;
+        }
+        else
+            rec->ln_u = lg;
+    }
+}
+
+// Hot scalars of a launch, packed so that the arguments every wavefront needs before its first memory
+// access fit the 16 dwords the command processor preloads into SGPRs (-amdgpu-kernarg-preload-count=16);
+// everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
+struct HotBits
+{
+    static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save)
+    {
+        return (uint32_t)dims | ((uint32_t)passes << 12) | ((uint32_t)color << 20) | ((uint32_t)vec_ok << 21) |
+               ((uint32_t)n_is_pow2 << 22) | ((uint32_t)use_ctl_save << 23);
+    }
+};
 
 template <class T, class Calc, int EPL, int LPW>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) stretch_half_step_kernel(const HalfStepArgs<T> a)
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
+                         int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
+    // `a` is the launch description in the kernarg segment; the h_* locals are the preloaded copies of the
+    // fields every wavefront needs before its first memory access (same values, no kernarg fetch)
+    const HalfStepArgs<T>& a = rest;
+    DrawRec<T>* const h_draws = hot_draws;
+    T* const h_pos = hot_pos;
+    T* const h_logp = hot_logp;
+    uint32_t* const h_n_accept = hot_n_accept;
+    const int h_n = hot_n;
+    const int h_dims = (int)(hot_bits & 0xFFFu);
+    const int h_passes = (int)((hot_bits >> 12) & 0xFFu);
+    const int h_color = (int)((hot_bits >> 20) & 1u);
+    const int h_vec_ok = (int)((hot_bits >> 21) & 1u);
+    const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
+    const int h_shard_begin = hot_shard_begin;
+    const int h_shard_count = hot_shard_count;
     static_assert((LPW & (LPW - 1)) == 0 && LPW >= 1 && LPW <= 64, "LPW must be a power of two <= 64");
     static_assert(EPL % Vec16<T>::N == 0, "EPL must be a whole number of 16-byte vectors");
+    static_assert(sizeof(DrawRec<T>) % 16 == 0, "draw records are read with 16-byte loads");
     constexpr int WPP = 64 / LPW;  // walkers per pass
 
-    // LDS carve-up (all dynamic, 16-byte aligned pieces): phase-A records | proposal stage | calculator tables
+    // LDS carve-up (all dynamic, 16-byte aligned pieces): proposal stage | calculator tables
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    PhaseA<T>* sh_a = reinterpret_cast<PhaseA<T>*>(smem);
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
     T* sh_block = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::block_offset());
 
@@ -218,76 +296,89 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) stretch_half_step_kernel(
     unsigned long long stamp_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     MCMCPP_STAMP(0);
+#ifdef MCMCPP_STAMPS
+    stamp_val[6] = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int wave = blockIdx.x * kWavesPerBlock + wib;
-    const int nw = WPP * a.passes;
+    const int nw = WPP * h_passes;
     const int first = wave * nw;  // first walker of this wavefront, relative to the shard
-    const bool wave_active = first < a.shard_count;
-    const int half_base = a.color ? a.n : 0;
-    const int other_base = a.color ? 0 : a.n;
+    const bool wave_active = first < h_shard_count;
+    const int half_base = h_color ? h_n : 0;
+    const int other_base = h_color ? 0 : h_n;
     const int sub = lane & (LPW - 1);
     const int grp = lane / LPW;
     const int i0 = sub * EPL;
-    const bool vec_ok = a.vec_ok != 0;
-    const int last_li = a.shard_count - 1;
+    const bool vec_ok = h_vec_ok != 0;
+    const int last_li = h_shard_count - 1;
 
-    // ---- every load that does not depend on the random draws is issued up front, so that the launch pays
-    //      one memory round trip for all of them: control record, run constants, jump-table entries,
-    //      current log-posterior and counter, the first pass's own rows and the calculator's tables
-    const StepCtl ctl = *a.ctl_in;  // wave-uniform
+    // ---- first round trip: everything that is addressed by the walker index alone --------------------------
+    const StepCtl ctl = *hot_ctl_in;  // wave-uniform
     const RunInfo run = *a.run;
 
     GroupCtx<T, EPL, LPW> ctx;
     ctx.sub = sub;
-    ctx.dims = a.dims;
+    ctx.dims = h_dims;
     ctx.lane = lane;
     ctx.stage = Calc::kNeedsStage ? &sh_stage[wib * 64 * EPL] : nullptr;
     ctx.vec_ok = vec_ok;
 
-    // phase-A work is spread over the wavefront's lanes: task t = 3*slot + k computes draw k of walker `slot`
+    // the draws of the NEXT update of this wavefront's walkers: task t = 3*slot + k is draw k of walker `slot`
     const int tasks = 3 * nw;
     const int slot_a = lane / 3, k_a = lane - 3 * slot_a;
-    const int i_a = a.shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
-    // small ensembles jump with one table entry per draw (one 128-bit multiply-add on the critical path),
-    // large ones compose a two-level table (256-walker blocks x position inside the block) with the draw offset
+    const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
+    // small ensembles jump with one table entry per draw (one 128-bit multiply-add), large ones compose a
+    // two-level table (256-walker blocks x position inside the block) with the draw offset
     const bool direct_jump = a.task_jump != nullptr;
-    Affine128 j_hi, j_lo;
+    Affine128 j_a, j_b;
     if (direct_jump)
-        j_hi = a.task_jump[3 * i_a + k_a];
+        j_a = a.task_jump[3 * i_a + k_a];
     else
     {
-        j_hi = a.jump_hi[i_a >> 8];
-        j_lo = a.jump_lo[i_a & 255];
+        j_a = a.jump_hi[i_a >> 8];
+        j_b = a.jump_lo[i_a & 255];
     }
+
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
 
     T own[EPL];
     T lp_old;
     uint32_t nacc_old = 0;
+    DrawRec<T> rec;
     {
         const int li0 = first + grp;
-        const bool act0 = wave_active && li0 < a.shard_count;
-        const int w0 = half_base + a.shard_begin + (act0 ? li0 : 0);
-        load_slice<T, EPL>(a.pos + (size_t)w0 * a.dims, i0, a.dims, vec_ok, act0, own);
-        lp_old = a.logp[w0];
-        if (sub == 0) nacc_old = a.n_accept[w0];
+        const bool act0 = wave_active && li0 < h_shard_count;
+        const int w0 = half_base + h_shard_begin + (act0 ? li0 : 0);
+        rec = h_draws[w0];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
+        load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
+        lp_old = h_logp[w0];
+        if (sub == 0) nacc_old = h_n_accept[w0];
     }
-    const bool has_block_scratch = Calc::block_scratch_elems(a.dims) != 0;
-    Calc::block_init(sh_block, a.calc_params, a.dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
+
+    // ---- second round trip: the partner rows of the first pass (needs only rec.partner) --------------------
+    T par[EPL];
+    load_slice<T, EPL>(h_pos + (size_t)(other_base + (int)rec.partner) * h_dims, i0, h_dims, vec_ok,
+                       wave_active && first + grp < h_shard_count, par);
+    MCMCPP_STAMP(1);  // records landed, partner gather issued (diagnostic build: also landed)
+
+    // ---- in its shadow: the calculator's tables, the hand-over to the next launch, the next draws -----------
+    const bool has_block_scratch = Calc::block_scratch_elems(h_dims) != 0;
+    Calc::block_commit(calc_pf, sh_block, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
     if (has_block_scratch) __syncthreads();
     ctx.block_scratch = has_block_scratch ? sh_block : nullptr;
-    // the calculator's per-lane registers (read from the LDS copy: they land while phase A computes)
     typename Calc::template Regs<EPL, LPW> cregs;
     Calc::template preload<EPL, LPW>(ctx, a.calc_params, cregs);
-    MCMCPP_STAMP(1);  // every up-front load has landed
 
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
         // hand the stream and the counters to the next half-step
         StepCtl nx = ctl;
         nx.state = apply(a.half_jump, ctl.state);
+        nx.state2 = apply(a.half_jump, ctl.state2);
         nx.half_step = ctl.half_step + 1;
-        if (a.color)
+        if (h_color)
         {
             // the ensemble step ends with the black half: advance the per-step counters
             const bool saved = ctl.save_phase + 1u == (uint32_t)run.interval;
@@ -304,107 +395,81 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) stretch_half_step_kernel(
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
         save_slot = a.direct_save_slot;
-    else if (a.use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
+    else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
 
-    PhaseA<T>& pa = sh_a[wib];
-
-    // ---------------- phase A: the three random draws of every walker of this wavefront ---------------
-    // Draw k of the walker at position i of the half is draw 3*i + k of this half-step (the order in which
-    // the reference's loop consumes its engine, EnsembleSampler.h:345-354 / StretchMove.h:102,104,113): the
-    // lane jumps the half-step's base state there directly.  k = 0: partner = engine(n); k = 1: z = Gw(u)
-    // and (D-1) ln z; k = 2: ln U = -(-log(1-u)/1).  One lane per draw keeps the dependent chain short.
-    for (int t = lane; t < tasks; t += 64)
-    {
-        const int slot = (t == lane) ? slot_a : t / 3;
-        const int k = (t == lane) ? k_a : t - 3 * slot;
-        if (first + slot < a.shard_count)
+    // Draws of this wavefront's walkers for their next update (half-step + 2, base state ctl.state2).  With one
+    // pass per wavefront the records being replaced were all read above, so the draws are computed here, in
+    // the shadow of the partner gather; with several passes the later passes still have to read theirs, so the
+    // draws wait until the update loop is done.
+    auto next_draws = [&]() {
+        for (int t = lane; t < tasks; t += 64)
         {
-            U128 s;
-            const int i = a.shard_begin + first + slot;
-            if (direct_jump)
-                s = apply(t == lane ? j_hi : a.task_jump[3 * i + k], ctl.state);
-            else
+            const int slot = (t == lane) ? slot_a : t / 3;
+            const int k = (t == lane) ? k_a : t - 3 * slot;
+            if (first + slot < h_shard_count)
             {
-                if (t == lane)
-                    s = apply(j_lo, apply(j_hi, ctl.state));
-                else
-                    s = apply(a.jump_lo[i & 255], apply(a.jump_hi[i >> 8], ctl.state));
-                const Affine128 dj = k == 0 ? a.draw_jump[0] : (k == 1 ? a.draw_jump[1] : a.draw_jump[2]);
-                s = apply(dj, s);
-            }
-            const uint64_t r = pcg_output(s);
-            if (k == 0)
-            {
-                if (r < a.redraw_threshold) atomicAdd(&a.diag->redraws, 1ULL);
-                pa.partner[slot] = a.n_is_pow2 ? (uint32_t)(r & (uint64_t)(a.n - 1)) : (uint32_t)(r % (uint64_t)a.n);
-            }
-            else
-            {
-                const T u = canonical(r, T());
-                const T tmp = a.gw_term1 * u + a.gw_inv_sqrt;
-                const T z = tmp * tmp;                 // GwDistribution.h:58
-                const T arg = (k == 1) ? z : (T)1 - u;  // one logarithm serves both kinds of lane
-                const T lg = dev_log(arg);
-                if (k == 1)
+                const int i = h_shard_begin + first + slot;
+                if (t != lane)
                 {
-                    pa.z[slot] = z;
-                    pa.zs[slot] = lg * a.dims_minus_one;  // StretchMove.h:110
+                    if (direct_jump)
+                        j_a = a.task_jump[3 * i + k];
+                    else
+                    {
+                        j_a = a.jump_hi[i >> 8];
+                        j_b = a.jump_lo[i & 255];
+                    }
                 }
-                else
-                    pa.ln_u[slot] = lg;
+                compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k, h_draws + half_base + i);
             }
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    MCMCPP_STAMP(2);  // phase A done
+    };
+    const bool draws_first = h_passes == 1;
+    if (draws_first) next_draws();
+    MCMCPP_STAMP(2);  // next draws done
 
-    // ---------------- phase B: LPW lanes per walker ------------------------------------------------
+    // ---------------- the update: LPW lanes per walker ------------------------------------------------------
     unsigned accepted_here = 0;
-    for (int q = 0; q < a.passes; ++q)
+    for (int q = 0; q < h_passes; ++q)
     {
-        const int slot = q * WPP + grp;  // walker slot inside the wavefront
-        const int li = first + slot;
-        const bool active = li < a.shard_count;
-        const int w = half_base + a.shard_begin + (active ? li : 0);
-        const uint32_t p = active ? pa.partner[slot] : 0u;
-        const T z = pa.z[slot];
+        const int li = first + q * WPP + grp;
+        const bool active = li < h_shard_count;
+        const int w = half_base + h_shard_begin + (active ? li : 0);
+        T* row = h_pos + (size_t)w * h_dims;
 
-        T* row = a.pos + (size_t)w * a.dims;
-        const T* prow = a.pos + (size_t)(other_base + (int)p) * a.dims;
-        T par[EPL], prop[EPL];
-        load_slice<T, EPL>(prow, i0, a.dims, vec_ok, active, par);
-
-        // the next pass's own rows and counters travel while this pass computes
+        // the next pass's record, own rows and counters travel while this pass computes
         T own_next[EPL];
         T lp_next = (T)0;
         uint32_t nacc_next = 0;
-        if (q + 1 < a.passes)
+        DrawRec<T> rec_next = rec;
+        if (q + 1 < h_passes)
         {
             const int lin = li + WPP;
-            const bool actn = lin < a.shard_count;
-            const int wn = half_base + a.shard_begin + (actn ? lin : 0);
-            load_slice<T, EPL>(a.pos + (size_t)wn * a.dims, i0, a.dims, vec_ok, actn, own_next);
-            lp_next = a.logp[wn];
-            if (sub == 0) nacc_next = a.n_accept[wn];
+            const bool actn = lin < h_shard_count;
+            const int wn = half_base + h_shard_begin + (actn ? lin : 0);
+            rec_next = h_draws[wn];
+            load_slice<T, EPL>(h_pos + (size_t)wn * h_dims, i0, h_dims, vec_ok, actn, own_next);
+            lp_next = h_logp[wn];
+            if (sub == 0) nacc_next = h_n_accept[wn];
         }
-
+        if (q > 0)
+            load_slice<T, EPL>(h_pos + (size_t)(other_base + (int)rec.partner) * h_dims, i0, h_dims, vec_ok, active, par);
         if (q == 0) MCMCPP_STAMP(3);  // partner rows landed
+
         // StretchMove.h:105-108  proposal = sel + z*(cur - sel); padded cells stay +0
+        T prop[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
         {
             const T d = own[e] - par[e];
-            const T zd = z * d;
+            const T zd = rec.z * d;
             prop[e] = par[e] + zd;
         }
         const T lp_new = Calc::template eval<EPL, LPW>(ctx, a.calc_params, cregs, prop);
         if (q == 0) MCMCPP_STAMP(4);  // calculator done
 
         // StretchMove.h:112-113  accept iff lnU < (probScaling + newProb) - oldProb
-        const T zs = pa.zs[slot], ln_u = pa.ln_u[slot];
+        const T zs = rec.zs, ln_u = rec.ln_u;
         const T delta = zs + lp_new - lp_old;
         const bool accept = active && (ln_u < delta);
         if (active && sub == 0)
@@ -416,37 +481,64 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) stretch_half_step_kernel(
         if (accept)
         {
             // Walker::jumpToNewPointSwap (Walker/Walker.h:172-179)
-            store_slice<T, EPL>(row, i0, a.dims, vec_ok, prop);
+            store_slice<T, EPL>(row, i0, h_dims, vec_ok, prop);
             if (sub == 0)
             {
-                a.logp[w] = lp_new;
-                a.n_accept[w] = nacc_old + 1u;
+                h_logp[w] = lp_new;
+                h_n_accept[w] = nacc_old + 1u;
             }
         }
         if (save_slot >= 0 && active)
         {
             // Walker -> Chain::storeWalker (Chain/ChainBlock.h:125-131): cell = slot*W*D + walker*D + p
-            T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * a.n) + (size_t)w) * a.dims;
+            T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * h_n) + (size_t)w) * h_dims;
             if (accept)
-                store_slice<T, EPL>(crow, i0, a.dims, vec_ok, prop);
+                store_slice<T, EPL>(crow, i0, h_dims, vec_ok, prop);
             else
-                store_slice<T, EPL>(crow, i0, a.dims, vec_ok, own);
+                store_slice<T, EPL>(crow, i0, h_dims, vec_ok, own);
         }
         accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
 #pragma unroll
         for (int e = 0; e < EPL; ++e) own[e] = own_next[e];
         lp_old = lp_next;
         nacc_old = nacc_next;
+        rec = rec_next;
     }
+    if (!draws_first) next_draws();
     MCMCPP_STAMP(5);  // all stores of this wavefront acknowledged
 #ifdef MCMCPP_STAMPS
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        stamp_val[7] = __builtin_amdgcn_s_memrealtime();  // 100 MHz constant clock, with [6] taken at entry
         for (int k = 0; k < 8; ++k) a.stamps[k] = stamp_val[k];
+    }
 #endif
     // per-wavefront accepted count of this half-step; summed per ensemble step by accepted_reduce_kernel
     // (one plain store per wavefront: thousands of same-address atomics would serialise for ~12 ns each)
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
-        a.partials[((size_t)ctl.partial_slot * 2 + (size_t)a.color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
+        a.partials[((size_t)ctl.partial_slot * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
+}
+
+// Fills the draw records of one colour for the half-step whose base engine state is `base` (one thread per
+// draw).  Run by the host for the first two half-steps after set_state / at the start of run(); from then on
+// every half-step launch leaves the records of its colour's next update behind.
+template <class T>
+__global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a, U128 base)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * a.shard_count) return;
+    const int slot = t / 3, k = t - 3 * slot;
+    const int i = a.shard_begin + slot;
+    const bool direct = a.task_jump != nullptr;
+    Affine128 j_a, j_b;
+    if (direct)
+        j_a = a.task_jump[3 * i + k];
+    else
+    {
+        j_a = a.jump_hi[i >> 8];
+        j_b = a.jump_lo[i & 255];
+    }
+    compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + (a.color ? a.n : 0) + i);
 }
 
 // Sums the per-wavefront accepted counts of the last `count` ensemble steps into RunInfo.accepted_per_step.
@@ -482,7 +574,9 @@ calc_logp_kernel(const T* pos, T* out, const T* calc_params, long long count, in
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
     T* sh_block = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::block_offset());
     const bool has_block_scratch = Calc::block_scratch_elems(dims) != 0;
-    Calc::block_init(sh_block, calc_params, dims, vec_ok != 0, (int)threadIdx.x, 64 * kWavesPerBlock);
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, calc_params, dims, vec_ok != 0, (int)threadIdx.x, 64 * kWavesPerBlock);
+    Calc::block_commit(calc_pf, sh_block, calc_params, dims, vec_ok != 0, (int)threadIdx.x, 64 * kWavesPerBlock);
     if (has_block_scratch) __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;

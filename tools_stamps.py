@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from mcmcpp_amd import capi
 from oracle import pyoracle as po
 import bench
-names = ["entry->loads landed", "phase A (rng, log)", "partner rows landed", "calculator", "accept+stores drained"]
+names = ["entry->partner gather issued", "tables+next draws", "wait partner rows", "calculator", "accept+stores issued"]
 for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
     D = 32
     P = bench.ar1_precision(D, 0.5)
@@ -22,6 +22,6 @@ for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
         capi.lib().mcmcpp_hip_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
         assert capi.lib().mcmcpp_hip_debug_stamps(s.h, out) == 0
         t = np.array(list(out)[:6], dtype=np.float64)
-        acc.append(np.diff(t))
+        acc.append(np.append(np.diff(t), [(out[5] - out[0]) / max(1, (out[7] - out[6])) * 100.0]))
     d = np.median(np.array(acc), axis=0)
-    print(calc, W, " | ".join("%s %.0f" % (n, x) for n, x in zip(names, d)), "| total %.0f ticks (s_memtime)" % d.sum())
+    print(calc, W, " | ".join("%s %.0f" % (n, x) for n, x in zip(names, d[:5])), "| total %.0f ticks (s_memtime) | shader clock ~%.0f MHz" % (d[:5].sum(), d[5]))
