@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--interval", type=int, default=100, help="slicing interval (one stored step per interval)")
     ap.add_argument("--walkers", type=int, default=16384)
     ap.add_argument("--dims", type=int, default=32)
-    ap.add_argument("--cpu-sample-steps", type=int, default=100)
+    ap.add_argument("--cpu-sample-steps", type=int, default=1000,
+                    help="ensemble steps of the workload timed on the CPU (about 20 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-chain", action="store_true", help="experiments only: store nothing")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")

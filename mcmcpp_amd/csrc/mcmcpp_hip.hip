@@ -291,7 +291,7 @@ public:
             HIP_TRY(hipMemcpy(d_task_jump, tj.data(), sizeof(Affine128) * tj.size(), hipMemcpyHostToDevice));
         }
 
-        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 32) : c.graph_steps;
+        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 64) : c.graph_steps;
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)grid_blocks() * kWavesPerBlock;
         HIP_TRY(hipMalloc(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));

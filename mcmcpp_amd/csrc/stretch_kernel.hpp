@@ -314,15 +314,33 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     const int last_li = h_shard_count - 1;
 
     // ---- first round trip: everything that is addressed by the walker index alone --------------------------
-    const StepCtl ctl = *hot_ctl_in;  // wave-uniform
-    const RunInfo run = *a.run;
-
+    // Issued first, from preloaded arguments only (no kernarg fetch in front of them): the draw record (whose
+    // partner index the second round trip waits for), own rows, log-posterior, counter.
     GroupCtx<T, EPL, LPW> ctx;
     ctx.sub = sub;
     ctx.dims = h_dims;
     ctx.lane = lane;
     ctx.stage = Calc::kNeedsStage ? &sh_stage[wib * 64 * EPL] : nullptr;
     ctx.vec_ok = vec_ok;
+
+    T own[EPL];
+    T lp_old;
+    uint32_t nacc_old = 0;
+    DrawRec<T> rec;
+    {
+        const int li0 = first + grp;
+        const bool act0 = wave_active && li0 < h_shard_count;
+        const int w0 = half_base + h_shard_begin + (act0 ? li0 : 0);
+        rec = h_draws[w0];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
+        load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
+        lp_old = h_logp[w0];
+        if (sub == 0) nacc_old = h_n_accept[w0];
+    }
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
+
+    const StepCtl ctl = *hot_ctl_in;  // wave-uniform
+    const RunInfo run = *a.run;
 
     // the draws of the NEXT update of this wavefront's walkers: task t = 3*slot + k is draw k of walker `slot`
     const int tasks = 3 * nw;
@@ -338,23 +356,6 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     {
         j_a = a.jump_hi[i_a >> 8];
         j_b = a.jump_lo[i_a & 255];
-    }
-
-    typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
-
-    T own[EPL];
-    T lp_old;
-    uint32_t nacc_old = 0;
-    DrawRec<T> rec;
-    {
-        const int li0 = first + grp;
-        const bool act0 = wave_active && li0 < h_shard_count;
-        const int w0 = half_base + h_shard_begin + (act0 ? li0 : 0);
-        rec = h_draws[w0];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
-        load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
-        lp_old = h_logp[w0];
-        if (sub == 0) nacc_old = h_n_accept[w0];
     }
 
     // ---- second round trip: the partner rows of the first pass (needs only rec.partner) --------------------
@@ -485,6 +486,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
             if (sub == 0)
             {
                 h_logp[w] = lp_new;
+                asm volatile("" : "+v"(nacc_old));  // keep the +1 here: computed at the load it would drain every load
                 h_n_accept[w] = nacc_old + 1u;
             }
         }

@@ -2,8 +2,9 @@
 """Diagnostic: where one wavefront of a half-step launch spends its cycles (needs make -C mcmcpp_amd/csrc STAMPS=1)."""
 import ctypes as C, os, sys
 import numpy as np
-os.environ["MCMCPP_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mcmcpp_amd", "libmcmcpp_hip_stamps.so")
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MCMCPP_HIP_LIB"] = os.path.join(ROOT, "mcmcpp_amd", "libmcmcpp_hip_stamps.so")
+sys.path.insert(0, ROOT)
 from mcmcpp_amd import capi
 from oracle import pyoracle as po
 import bench

@@ -1,4 +1,6 @@
 #!/bin/bash
+# usage (from the repo root, on the GPU box): tools/sweep.sh <tag> < tools/sweep_walkers.txt
+# each input line: <name> <ENV=VALUE> <bench.py arguments...>; prints one compact line per run
 tag=$1
 p() { python - "$1" "$2" <<'PY'
 import json,sys
