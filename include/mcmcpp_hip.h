@@ -54,6 +54,9 @@ enum {
     MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D = 3 /* params: epsilon; requires D == 2 */
 };
 
+/* calculator ids from here on belong to user plug-ins (mcmcpp_hip_register_calculator) */
+#define MCMCPP_HIP_CALC_USER_BASE 1000
+
 typedef struct mcmcpp_hip_sampler mcmcpp_hip_sampler;
 
 /* Stands in for the constructor arguments of EnsembleSampler (EnsembleSampler.h:66-67,199-218),
@@ -91,6 +94,14 @@ typedef struct mcmcpp_hip_config {
 /* launch every kernel and copy on the caller's stream (config.hip_stream), so that the caller's own work on
  * that stream -- e.g. RCCL collectives issued through torch.distributed -- is ordered with the half-steps */
 #define MCMCPP_HIP_FLAG_CALLER_STREAM 1u
+
+/* User-compiled device Calculators (the reference takes the Calculator as a template argument of the Mover,
+ * Movers/StretchMove.h:42-43; here it is a device functor built with hipcc against
+ * mcmcpp_amd/csrc/mcmcpp_hip_plugin.hpp).  table_f64 / table_f32 are what the plug-in's
+ * mcmcpp_hip_plugin_<name>_f64() / _f32() return (either may be NULL); calc_id >= MCMCPP_HIP_CALC_USER_BASE;
+ * params_len >= 0 makes mcmcpp_hip_create insist on exactly that many parameters, -1 accepts any.
+ * Registering an id again replaces it (handles created earlier keep what they were created with). */
+int mcmcpp_hip_register_calculator(int32_t calc_id, const void* table_f64, const void* table_f32, int32_t params_len);
 
 /* EnsembleSampler::EnsembleSampler / ~EnsembleSampler */
 int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out);

@@ -14,7 +14,7 @@ OK = 0
 
 # every symbol include/mcmcpp_hip.h declares
 EXPORTS = [
-    "mcmcpp_hip_abi_version", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
+    "mcmcpp_hip_abi_version", "mcmcpp_hip_register_calculator", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
     "mcmcpp_hip_set_state", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
     "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing",
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
@@ -61,6 +61,7 @@ def lib():
         L = C.CDLL(path)
         vp, i32, i64, u64p = C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_uint64)
         L.mcmcpp_hip_abi_version.restype = C.c_int
+        L.mcmcpp_hip_register_calculator.argtypes = [i32, vp, vp, i32]
         L.mcmcpp_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
         L.mcmcpp_hip_destroy.argtypes = [vp]
         L.mcmcpp_hip_destroy.restype = None

@@ -1,0 +1,67 @@
+// launch_build.hpp -- instantiates the kernels of one (element type, calculator functor) pair and builds the
+// host-side launch table over them.  Used by the library's own instantiation units (instances.inc) and by
+// user plug-ins (mcmcpp_hip_plugin.hpp).
+#pragma once
+
+#include "launch_table.hpp"
+
+namespace mcmcpp
+{
+namespace build
+{
+template <class T, class Calc, int EPL, int LPW>
+void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save);
+    hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.draws,
+                       a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+}
+
+template <class T, class Calc, int EPL, int LPW>
+void launch_calc(const T* pos, T* out, const T* prm, long long count, int dims, int vec_ok, unsigned grid, hipStream_t st)
+{
+    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(dims);
+    hipLaunchKernelGGL((calc_logp_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, pos, out, prm,
+                       count, dims, vec_ok);
+}
+
+template <class T, class Calc, int LPWLOG, int EPLSHIFT>
+void put(LaunchTable<T>& t)
+{
+    constexpr int kBase = Vec16<T>::N;
+    t.half_step[LPWLOG][EPLSHIFT] = &launch_half<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+    t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+}
+
+// OnlyLpw1: only the single-lane mapping is meaningful (a fixed low-dimensional target such as D = 2)
+template <class T, class Calc, bool OnlyLpw1>
+LaunchTable<T> make()
+{
+    LaunchTable<T> t = {};
+    t.abi = kLaunchTableAbi;
+    t.elem_size = (uint32_t)sizeof(T);
+    put<T, Calc, 0, 0>(t);
+    if constexpr (!OnlyLpw1)
+    {
+        put<T, Calc, 1, 0>(t);
+        put<T, Calc, 2, 0>(t);
+        put<T, Calc, 3, 0>(t);
+        put<T, Calc, 4, 0>(t);
+        put<T, Calc, 5, 0>(t);
+        put<T, Calc, 6, 0>(t);
+        put<T, Calc, 6, 1>(t);
+        put<T, Calc, 6, 2>(t);
+        if constexpr (sizeof(T) == 8) put<T, Calc, 6, 3>(t);  // D up to 1024 in both element types
+    }
+    return t;
+}
+}  // namespace build
+
+template <class T, template <class> class CalcT, bool OnlyLpw1 = false>
+const LaunchTable<T>* make_launch_table()
+{
+    static const LaunchTable<T> table = build::make<T, CalcT<T>, OnlyLpw1>();
+    return &table;
+}
+}  // namespace mcmcpp

@@ -12,9 +12,13 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
+constexpr uint32_t kLaunchTableAbi = 0x4D430001u;  // bumped whenever HalfStepArgs or the launcher signatures change
+
 template <class T>
 struct LaunchTable
 {
+    uint32_t abi;        // kLaunchTableAbi of the headers the table was built from
+    uint32_t elem_size;  // sizeof(T)
     typedef void (*HalfStepFn)(const HalfStepArgs<T>&, unsigned grid, hipStream_t);
     typedef void (*CalcFn)(const T* pos, T* out, const T* params, long long count, int dims, int vec_ok, unsigned grid,
                            hipStream_t);

@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -55,6 +57,24 @@ long env_long(const char* name, long fallback)
     return (v && *v) ? std::strtol(v, nullptr, 10) : fallback;
 }
 
+struct RegisteredCalc
+{
+    const void* f64;
+    const void* f32;
+    int params_len;
+};
+std::mutex g_registry_mutex;
+std::map<int, RegisteredCalc> g_registry;
+
+bool registered_calc(int calc_id, RegisteredCalc* out)
+{
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    std::map<int, RegisteredCalc>::const_iterator it = g_registry.find(calc_id);
+    if (it == g_registry.end()) return false;
+    if (out) *out = it->second;
+    return true;
+}
+
 template <class T>
 const LaunchTable<T>* table_for(int calc_id);
 template <>
@@ -66,7 +86,11 @@ const LaunchTable<double>* table_for<double>(int calc_id)
     case MCMCPP_HIP_CALC_DENSE_GAUSSIAN: return launch_table_f64_dense();
     case MCMCPP_HIP_CALC_ROSENBROCK: return launch_table_f64_rosenbrock();
     case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D: return launch_table_f64_skewed();
-    default: return nullptr;
+    default:
+    {
+        RegisteredCalc r;
+        return registered_calc(calc_id, &r) ? static_cast<const LaunchTable<double>*>(r.f64) : nullptr;
+    }
     }
 }
 template <>
@@ -78,7 +102,11 @@ const LaunchTable<float>* table_for<float>(int calc_id)
     case MCMCPP_HIP_CALC_DENSE_GAUSSIAN: return launch_table_f32_dense();
     case MCMCPP_HIP_CALC_ROSENBROCK: return launch_table_f32_rosenbrock();
     case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D: return launch_table_f32_skewed();
-    default: return nullptr;
+    default:
+    {
+        RegisteredCalc r;
+        return registered_calc(calc_id, &r) ? static_cast<const LaunchTable<float>*>(r.f32) : nullptr;
+    }
     }
 }
 }  // namespace
@@ -157,7 +185,9 @@ public:
         D = c.num_params;
         n = W / 2;
         table = table_for<T>(c.calc_id);
-        if (!table) return fail(MCMCPP_HIP_E_ARG, "unknown calc_id %d", c.calc_id);
+        if (!table) return fail(MCMCPP_HIP_E_ARG, "calc_id %d has no kernels for this element type", c.calc_id);
+        if (table->abi != kLaunchTableAbi || table->elem_size != sizeof(T))
+            return fail(MCMCPP_HIP_E_ARG, "calc_id %d: the plug-in was built against other headers (table abi %08x)", c.calc_id, table->abi);
 
         // lane mapping: LPW lanes x EPL elements cover the walker's D-vector padded to a power of two
         const int base = Vec16<T>::N;
@@ -847,7 +877,13 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
     case MCMCPP_HIP_CALC_SKEWED_GAUSSIAN_2D:
         if (!c->calc_params || c->calc_params_len != 1 || c->num_params != 2) BAD("SkewedGaussian2D needs D == 2 and 1 parameter");
         break;
-    default: BAD("unknown calc_id %d", c->calc_id);
+    default:
+    {
+        RegisteredCalc r;
+        if (c->calc_id < MCMCPP_HIP_CALC_USER_BASE || !registered_calc(c->calc_id, &r)) BAD("unknown calc_id %d", c->calc_id);
+        if (r.params_len >= 0 && c->calc_params_len != r.params_len) BAD("calculator %d takes %d parameters", c->calc_id, r.params_len);
+        if (c->calc_params_len < 0 || (c->calc_params_len > 0 && !c->calc_params)) BAD("calc_params missing");
+    }
     }
     if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
     if (c->gw_alpha_num < 0 || c->gw_alpha_den < 0 || ((c->gw_alpha_num == 0) != (c->gw_alpha_den == 0)))
@@ -871,6 +907,29 @@ int mcmcpp_hip_debug_stamps(mcmcpp_hip_sampler* h, unsigned long long* out8)
     return h->debug_stamps(out8);
 }
 #endif
+
+int mcmcpp_hip_register_calculator(int32_t calc_id, const void* table_f64, const void* table_f32, int32_t params_len)
+{
+    if (calc_id < MCMCPP_HIP_CALC_USER_BASE || (!table_f64 && !table_f32) || params_len < -1)
+    {
+        g_create_error = "register_calculator: calc_id must be >= MCMCPP_HIP_CALC_USER_BASE with at least one table";
+        return MCMCPP_HIP_E_ARG;
+    }
+    const uint32_t a64 = table_f64 ? static_cast<const LaunchTable<double>*>(table_f64)->abi : kLaunchTableAbi;
+    const uint32_t a32 = table_f32 ? static_cast<const LaunchTable<float>*>(table_f32)->abi : kLaunchTableAbi;
+    if (a64 != kLaunchTableAbi || a32 != kLaunchTableAbi)
+    {
+        g_create_error = "register_calculator: the plug-in was built against other headers";
+        return MCMCPP_HIP_E_ARG;
+    }
+    RegisteredCalc r;
+    r.f64 = table_f64;
+    r.f32 = table_f32;
+    r.params_len = params_len;
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry[calc_id] = r;
+    return MCMCPP_HIP_OK;
+}
 
 int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out)
 {
