@@ -129,6 +129,12 @@ int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, voi
  * Any pointer may be NULL. */
 int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept);
 
+/* Checkpoint / resume.  The random stream has no per-walker state: (seed, stream, ensemble steps done) address
+ * every draw, so a checkpoint is get_state's arrays plus one integer.  After set_state (which rewinds to the
+ * first draw) this repositions the stream as if `ensemble_steps_done` steps had been executed, without touching
+ * walkers or counters.  (The reference cannot do this: its engine state is private to the Mover.) */
+int mcmcpp_hip_seek(mcmcpp_hip_sampler* h, uint64_t ensemble_steps_done);
+
 /* EnsembleSampler::reset (EnsembleSampler.h:312-322): zero the counters, keep positions and stream. */
 int mcmcpp_hip_reset_counters(mcmcpp_hip_sampler* h);
 

@@ -15,7 +15,7 @@ OK = 0
 # every symbol include/mcmcpp_hip.h declares
 EXPORTS = [
     "mcmcpp_hip_abi_version", "mcmcpp_hip_register_calculator", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
-    "mcmcpp_hip_set_state", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
+    "mcmcpp_hip_set_state", "mcmcpp_hip_seek", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
     "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing",
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
@@ -68,6 +68,7 @@ def lib():
         L.mcmcpp_hip_last_error.argtypes = [vp]
         L.mcmcpp_hip_last_error.restype = C.c_char_p
         L.mcmcpp_hip_set_state.argtypes = [vp, vp, vp]
+        L.mcmcpp_hip_seek.argtypes = [vp, C.c_uint64]
         L.mcmcpp_hip_run.argtypes = [vp, i64, i32, vp, vp]
         L.mcmcpp_hip_get_state.argtypes = [vp, vp, vp, vp]
         L.mcmcpp_hip_reset_counters.argtypes = [vp]
@@ -131,6 +132,9 @@ class HipSampler:
         logp = np.ascontiguousarray(logp, dtype=self.np_t)
         assert pos.size == self.W * self.D and logp.size == self.W
         self._check(lib().mcmcpp_hip_set_state(self.h, _ptr(pos), _ptr(logp)))
+
+    def seek(self, ensemble_steps_done):
+        self._check(lib().mcmcpp_hip_seek(self.h, ensemble_steps_done))
 
     def run(self, n_saved, interval=1, save_chain=True, want_accepted=True):
         chain = np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None

@@ -140,6 +140,7 @@ struct mcmcpp_hip_sampler
     virtual int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) = 0;
     virtual int get_state(void* pos, void* logp, uint32_t* n_accept) = 0;
     virtual int reset_counters() = 0;
+    virtual int seek(uint64_t steps_done) = 0;
     virtual int get_counters(uint64_t* accepted, uint64_t* steps, uint64_t* ties, uint64_t* redraws) = 0;
     virtual int calc_logp(const void* pos, int64_t count, void* out) = 0;
     virtual int last_run_timing(double* ms, int64_t* launches) = 0;
@@ -463,6 +464,15 @@ public:
         if (logp) HIP_TRY(hipMemcpy(logp, d_logp, sizeof(T) * (size_t)W, hipMemcpyDeviceToHost));
         if (n_accept) HIP_TRY(hipMemcpy(n_accept, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
         return MCMCPP_HIP_OK;
+    }
+
+    int seek(uint64_t steps_done) override
+    {
+        if (!have_state) return fail(MCMCPP_HIP_E_STATE, "seek: set_state has not been called");
+        if (steps_done > (~0ULL >> 2)) return fail(MCMCPP_HIP_E_ARG, "seek: step count out of range");
+        HIP_TRY(hipSetDevice(device));
+        half_steps = 2 * steps_done;
+        return write_ctl(0);  // repositions the stream and re-primes the draw records of the next two half-steps
     }
 
     int reset_counters() override
@@ -988,6 +998,11 @@ int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uin
 {
     NEED_H;
     return h->get_state(positions, logp, n_accept);
+}
+int mcmcpp_hip_seek(mcmcpp_hip_sampler* h, uint64_t ensemble_steps_done)
+{
+    NEED_H;
+    return h->seek(ensemble_steps_done);
 }
 int mcmcpp_hip_reset_counters(mcmcpp_hip_sampler* h)
 {

@@ -153,6 +153,22 @@ def test_resume_reset_and_unsaved_runs_are_seamless():
     assert int(nacc.sum()) == int(oa[30:].sum())               # counters restarted at the reset
 
 
+def test_checkpoint_and_resume_in_a_new_handle():
+    """get_state + the number of steps done is a complete checkpoint: a fresh handle resumes the trajectory."""
+    orc, hip = _oracle_and_hip(1024, 16, po.CALC_DENSE_GAUSSIAN, po.F64, seed=21, steps=0)
+    oc, oa = orc.run(70)
+    hip.run(25, save_chain=False, want_accepted=False)
+    pos, logp, _ = hip.get_state()
+    rng = np.random.default_rng(1024 + 16)
+    params = _params_for(po.CALC_DENSE_GAUSSIAN, 16, np.float64, rng)
+    fresh = capi.HipSampler(1024, 16, po.CALC_DENSE_GAUSSIAN, params, seed=21)
+    fresh.set_state(pos, logp)
+    fresh.seek(25)
+    chain, acc = fresh.run(45)
+    np.testing.assert_array_equal(chain, oc[25:])
+    np.testing.assert_array_equal(acc, oa[25:])
+
+
 def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
     base = None
     for env in [{}, {"MCMCPP_HIP_PASSES": "1"}, {"MCMCPP_HIP_PASSES": "4"}, {"MCMCPP_HIP_PASSES": "16"},
