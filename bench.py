@@ -155,11 +155,21 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal only (MCMCPP_BENCH_BACKEND=gloo): several ranks may share the GPUs of a smaller box; the driver's
+    # multi-GPU runs use the default, RCCL ("nccl"), one rank per GPU.
+    backend = os.environ.get("MCMCPP_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("%d ranks but %d GPUs visible" % (world, torch.cuda.device_count()))
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     from mcmcpp_amd import capi
     from oracle import pyoracle as po  # initial positions only (pure integer-hash recipe)
@@ -202,14 +212,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    from mcmcpp_amd import distributed as md
     walker_steps = float(W) * args.batch * args.steps
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        s = torch.tensor([walker_steps, float(accepted), gpu_ms, float(launches)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        walker_steps, accepted, gpu_ms, launches = [float(x) for x in s.tolist()]
+    # whole-job aggregate: sum of the ranks' work / slowest rank's time (tests/test_split_gloo.py covers this helper)
+    _, elapsed, walker_steps, (accepted, gpu_ms, launches) = md.aggregate_throughput(
+        elapsed, walker_steps, [float(accepted), gpu_ms, float(launches)], device=reduce_device)
 
     if rank == 0:
         bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8          # 784 B at D = 32, fp64
