@@ -108,6 +108,11 @@ template <class T>
 struct IsoGaussianFn
 {
     static constexpr bool kNeedsStage = false;
+    template <int EPL, int LPW>
+    struct MatrixCore
+    {
+        static constexpr bool kUse = false;
+    };
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
     struct Prefetch
     {
@@ -145,6 +150,12 @@ struct DenseGaussianFn
 {
     static constexpr bool kNeedsStage = true;
     static constexpr int kMaxPadded = 64;
+    // fp64 walkers of 17..32 dimensions take the matrix-core kernel (stretch_half_step_mfma_kernel)
+    template <int EPL, int LPW>
+    struct MatrixCore
+    {
+        static constexpr bool kUse = sizeof(T) == 8 && EPL == 2 && LPW == 16;
+    };
 
     __host__ __device__ static int padded_dim(int D)
     {
@@ -296,6 +307,11 @@ template <class T>
 struct RosenbrockFn
 {
     static constexpr bool kNeedsStage = false;
+    template <int EPL, int LPW>
+    struct MatrixCore
+    {
+        static constexpr bool kUse = false;
+    };
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
     struct Prefetch
     {
@@ -342,6 +358,11 @@ template <class T>
 struct SkewedGaussian2DFn
 {
     static constexpr bool kNeedsStage = false;
+    template <int EPL, int LPW>
+    struct MatrixCore
+    {
+        static constexpr bool kUse = false;
+    };
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
     struct Prefetch
     {

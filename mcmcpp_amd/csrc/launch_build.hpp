@@ -19,6 +19,15 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 }
 
 template <class T, class Calc, int EPL, int LPW>
+void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = (size_t)kWavesPerBlock * 16 * 33 * sizeof(T);
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save);
+    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st,
+                       a.draws, a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+}
+
+template <class T, class Calc, int EPL, int LPW>
 void launch_calc(const T* pos, T* out, const T* prm, long long count, int dims, int vec_ok, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(dims);
@@ -31,6 +40,11 @@ void put(LaunchTable<T>& t)
 {
     constexpr int kBase = Vec16<T>::N;
     t.half_step[LPWLOG][EPLSHIFT] = &launch_half<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+    if constexpr (Calc::template MatrixCore<(kBase << EPLSHIFT), (1 << LPWLOG)>::kUse)
+    {
+        t.half_step_mc[LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+        t.mc_passes[LPWLOG][EPLSHIFT] = 4;
+    }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
 }
 

@@ -235,6 +235,16 @@ public:
         }
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;
+        // Matrix-core variant of the half-step kernel (dense calculators, even D): 16 walkers per wavefront.  It
+        // needs a quarter of the wavefronts, so it only pays once the plain kernel would fill the chip several
+        // times over (measured: 16 384 walkers 6.0 vs 5.4 us per launch, 65 536 walkers 8.8 vs 12.0, 262 144
+        // walkers 28 vs 39 us).
+        const long mc_min = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 32768);
+        if (table->half_step_mc[lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
+        {
+            half_fn = table->half_step_mc[lpw_log][epl_shift];
+            passes = table->mc_passes[lpw_log][epl_shift];
+        }
 
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
         {

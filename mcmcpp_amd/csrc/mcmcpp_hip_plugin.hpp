@@ -9,6 +9,7 @@
 //     #include "mcmcpp_hip_plugin.hpp"
 //     template <class T> struct MyTarget {                       // see calculators.hpp for the built-in ones
 //         static constexpr bool kNeedsStage = false;             // true: ctx.publish()/ctx.element(j) are used
+//         template <int EPL, int LPW> struct MatrixCore { static constexpr bool kUse = false; };
 //         __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
 //         struct Prefetch {};
 //         __device__ static void block_prefetch(Prefetch&, const T*, int, bool, int, int) {}

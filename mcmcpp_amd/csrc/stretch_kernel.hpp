@@ -334,7 +334,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         rec = h_draws[w0];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
         load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
         lp_old = h_logp[w0];
-        if (sub == 0) nacc_old = h_n_accept[w0];
+        nacc_old = h_n_accept[w0];  // every lane of the group reads the same word: no divergent branch, no wait
     }
     typename Calc::Prefetch calc_pf;
     Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
@@ -451,7 +451,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
             rec_next = h_draws[wn];
             load_slice<T, EPL>(h_pos + (size_t)wn * h_dims, i0, h_dims, vec_ok, actn, own_next);
             lp_next = h_logp[wn];
-            if (sub == 0) nacc_next = h_n_accept[wn];
+            nacc_next = h_n_accept[wn];
         }
         if (q > 0)
             load_slice<T, EPL>(h_pos + (size_t)(other_base + (int)rec.partner) * h_dims, i0, h_dims, vec_ok, active, par);
@@ -541,6 +541,249 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
         j_b = a.jump_lo[i & 255];
     }
     compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + (a.color ? a.n : 0) + i);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Matrix-core variant for calculators whose log-posterior contains a dense D x D product (the correlated
+// Gaussian): a wavefront updates 16 walkers at once and evaluates  Y = X * P^T  ([16 walkers x 32] x [32 x 32])
+// with v_mfma_f64_16x16x4_f64.  On gfx950 that instruction is, bit for bit, the fma chain in ascending k
+// starting from the C operand (tools/mfma_probe.hip), i.e. exactly the host Calculator's
+// `acc = fma(P[i][j], x[j], acc)` loop, so parity is unchanged.  Everything else (draw records one update
+// ahead, two memory round trips, in-place accept, chain store, accepted partials) is as in the kernel above.
+// Operand layout (measured): A lane l -> [m = l%16][k = l/16]; B lane l -> [k = l/16][n = l%16];
+// C/D lane l, register r -> [m = 4r + l/16][n = l%16].  Walker slot (pass q, lane group g) is matrix row
+// 4q + g, so its result comes back in register q of the very lanes that apply the accept.
+// ---------------------------------------------------------------------------------------------------------
+typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+
+template <class T, class Calc, int EPL, int LPW>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
+                              int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
+{
+    static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
+    constexpr int P = 4;        // passes: 4 lane groups x 4 passes = 16 walkers = one MFMA tile of rows
+    constexpr int N2 = 32;      // padded dimension
+    constexpr int XS = 33;      // row stride of the staged proposals (doubles): odd, to spread LDS banks
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (16 * XS);
+
+    const HalfStepArgs<T>& a = rest;
+#ifdef MCMCPP_STAMPS
+    unsigned long long stamp_val[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    stamp_val[6] = __builtin_amdgcn_s_memrealtime();
+#endif
+    MCMCPP_STAMP(0);
+    DrawRec<T>* const h_draws = hot_draws;
+    T* const h_pos = hot_pos;
+    T* const h_logp = hot_logp;
+    uint32_t* const h_n_accept = hot_n_accept;
+    const int h_n = hot_n;
+    const int h_dims = (int)(hot_bits & 0xFFFu);
+    const int h_color = (int)((hot_bits >> 20) & 1u);
+    const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
+    const int h_shard_begin = hot_shard_begin;
+    const int h_shard_count = hot_shard_count;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int first = wave * 16;
+    const bool wave_active = first < h_shard_count;
+    if (!wave_active) return;  // no workgroup-wide barrier in this kernel
+    const int half_base = h_color ? h_n : 0;
+    const int other_base = h_color ? 0 : h_n;
+    const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
+    // (the host only selects this kernel for even D: rows are whole 16-byte pieces, every access is branch-free)
+    typedef double2 V2;
+    const bool col_ok = i0 < h_dims;
+    const int i0c = col_ok ? i0 : 0;
+    const int last_li = h_shard_count - 1;
+
+    // ---- first round trip: draw records, own rows, log-posteriors, counters of all four passes --------------
+    DrawRec<T> rec[P];
+    T own[P][2];
+    T lp_old[P];
+    uint32_t nacc_old[P];
+    bool active[P];
+    int w[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const int li = first + 4 * q + grp;
+        active[q] = li < h_shard_count;
+        w[q] = half_base + h_shard_begin + (active[q] ? li : 0);
+        rec[q] = h_draws[w[q]];
+        {
+            const V2 v = *reinterpret_cast<const V2*>(h_pos + (size_t)w[q] * h_dims + i0c);
+            own[q][0] = (active[q] && col_ok) ? v.x : (T)0;
+            own[q][1] = (active[q] && col_ok) ? v.y : (T)0;
+        }
+        lp_old[q] = h_logp[w[q]];
+        nacc_old[q] = h_n_accept[w[q]];  // every lane of the group reads the same word: no divergent branch, no wait
+    }
+    // B fragments of P^T (params hold P transposed, row j = P^T[j][.]): this lane's cell of every 4x16 block
+    T bfrag[2][8];
+    {
+        const T* pt = a.calc_params;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+        {
+            const int k = 4 * ks + grp;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+            {
+                const int nn = 16 * nt + sub;
+                const bool inside = k < h_dims && nn < h_dims;
+                const T v = pt[(size_t)(inside ? k : 0) * h_dims + (inside ? nn : 0)];
+                bfrag[nt][ks] = inside ? v : (T)0;
+            }
+        }
+    }
+    const StepCtl ctl = *hot_ctl_in;
+    const RunInfo run = *a.run;
+    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;  // 48 of the 64 lanes compute the 16 walkers' next draws
+    const int i_a = h_shard_begin + min(first + slot_a, last_li);
+    const bool direct_jump = a.task_jump != nullptr;
+    Affine128 j_a, j_b;
+    if (direct_jump)
+        j_a = a.task_jump[3 * i_a + k_a];
+    else
+    {
+        j_a = a.jump_hi[i_a >> 8];
+        j_b = a.jump_lo[i_a & 255];
+    }
+
+    // ---- second round trip: the partner rows of all four passes ------------------------------------------------
+    T par[P][2];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const int pw = other_base + (active[q] ? (int)rec[q].partner : 0);
+        const V2 v = *reinterpret_cast<const V2*>(h_pos + (size_t)pw * h_dims + i0c);
+        par[q][0] = (active[q] && col_ok) ? v.x : (T)0;
+        par[q][1] = (active[q] && col_ok) ? v.y : (T)0;
+    }
+
+    MCMCPP_STAMP(1);  // records landed, partner gather issued
+    // ---- in its shadow: hand-over to the next launch and the draws of these walkers' next update ----------------
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        StepCtl nx = ctl;
+        nx.state = apply(a.half_jump, ctl.state);
+        nx.state2 = apply(a.half_jump, ctl.state2);
+        nx.half_step = ctl.half_step + 1;
+        if (h_color)
+        {
+            const bool saved = ctl.save_phase + 1u == (uint32_t)run.interval;
+            nx.step_in_run = ctl.step_in_run + 1;
+            nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
+            nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
+            nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
+        }
+        *a.ctl_out = nx;
+    }
+    long long save_slot = -1;
+    if (a.direct_save_slot >= 0)
+        save_slot = a.direct_save_slot;
+    else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
+        save_slot = run.chain_slot_base + ctl.chain_slot;
+    if (lane < 48 && first + slot_a < h_shard_count)
+        compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws + half_base + h_shard_begin + first + slot_a);
+
+    MCMCPP_STAMP(2);  // next draws done
+    // ---- proposals (StretchMove.h:105-108), staged as rows of X ---------------------------------------------------
+    T prop[P][2];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+            const T d = own[q][e] - par[q][e];
+            const T zd = rec[q].z * d;
+            prop[q][e] = par[q][e] + zd;
+        }
+        T* xr = sh_x + (4 * q + grp) * XS + i0;
+        xr[0] = prop[q][0];
+        xr[1] = prop[q][1];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    MCMCPP_STAMP(3);  // partner rows landed, proposals staged
+    // ---- Y = X * P^T on the matrix cores: 8 k-steps x 2 column tiles, k ascending (the host's fma order) ------------
+    mfma_f64x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+    {
+        const double xa = sh_x[sub * XS + 4 * ks + grp];  // A[m = lane%16][k = 4ks + lane/16]
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bfrag[0][ks], y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bfrag[1][ks], y1, 0, 0, 0);
+    }
+    // t[m][n] = x[m][n] * y[m][n], then the canonical tree over n: tree16(columns 0..15) + tree16(columns 16..31)
+    T lp_new[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+    {
+        const int m = 4 * r + grp;
+        const T x0 = sh_x[m * XS + sub], x1 = sh_x[m * XS + 16 + sub];
+        T t0 = (sub < h_dims) ? x0 * y0[r] : (T)0;
+        T t1 = (16 + sub < h_dims) ? x1 * y1[r] : (T)0;
+        t0 = t0 + dpp_move<0xB1>(t0);
+        t1 = t1 + dpp_move<0xB1>(t1);
+        t0 = t0 + dpp_move<0x4E>(t0);
+        t1 = t1 + dpp_move<0x4E>(t1);
+        t0 = t0 + dpp_move<0x141>(t0);
+        t1 = t1 + dpp_move<0x141>(t1);
+        t0 = t0 + dpp_move<0x140>(t0);
+        t1 = t1 + dpp_move<0x140>(t1);
+        lp_new[r] = (T)-0.5 * (t0 + t1);
+    }
+
+    MCMCPP_STAMP(4);  // calculator done
+    // ---- Metropolis accept in place, chain store, counters ------------------------------------------------------------
+    unsigned accepted_here = 0;
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const T zs = rec[q].zs, ln_u = rec[q].ln_u;
+        const T delta = zs + lp_new[q] - lp_old[q];
+        const bool accept = active[q] && (ln_u < delta);
+        if (active[q] && sub == 0)
+        {
+            const T margin = dev_abs(ln_u - delta);
+            const T scale = dev_abs(ln_u) + dev_abs(zs) + dev_abs(lp_new[q]) + dev_abs(lp_old[q]);
+            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+        }
+        T* row = h_pos + (size_t)w[q] * h_dims;
+        if (accept)
+        {
+            if (col_ok) *reinterpret_cast<V2*>(row + i0) = make_double2(prop[q][0], prop[q][1]);
+            if (sub == 0)
+            {
+                h_logp[w[q]] = lp_new[q];
+                h_n_accept[w[q]] = nacc_old[q] + 1u;
+            }
+        }
+        if (save_slot >= 0 && active[q])
+        {
+            T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * h_n) + (size_t)w[q]) * h_dims;
+            if (col_ok)
+                *reinterpret_cast<V2*>(crow + i0) = accept ? make_double2(prop[q][0], prop[q][1]) : make_double2(own[q][0], own[q][1]);
+        }
+        accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
+    }
+    MCMCPP_STAMP(5);
+#ifdef MCMCPP_STAMPS
+    if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    {
+        stamp_val[7] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 8; ++k) a.stamps[k] = stamp_val[k];
+    }
+#endif
+    if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
+        a.partials[((size_t)ctl.partial_slot * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
 }
 
 // Sums the per-wavefront accepted counts of the last `count` ensemble steps into RunInfo.accepted_per_step.

@@ -7,6 +7,11 @@ template <class T>
 struct NoTables
 {
     static constexpr bool kNeedsStage = false;
+    template <int EPL, int LPW>
+    struct MatrixCore
+    {
+        static constexpr bool kUse = false;
+    };
     __host__ __device__ static size_t block_scratch_elems(int) { return 0; }
     struct Prefetch
     {

@@ -153,6 +153,19 @@ def test_resume_reset_and_unsaved_runs_are_seamless():
     assert int(nacc.sum()) == int(oa[30:].sum())               # counters restarted at the reset
 
 
+@pytest.mark.parametrize("W,D", [(4096 + 6, 32), (600, 18), (2048, 26)])
+def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D):
+    """The f64 MFMA variant of the half-step kernel (normally only used for large dense ensembles) against the
+    oracle, including ragged last wavefronts and padded dimensions (17 <= D <= 32, even)."""
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "0")
+    orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, po.F64, seed=77, steps=0)
+    oc, oa = orc.run(30, interval=2, mode=po.MODE_COUNTER, threads=4)
+    hc, ha = hip.run(30, interval=2)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip)
+
+
 def test_checkpoint_and_resume_in_a_new_handle():
     """get_state + the number of steps done is a complete checkpoint: a fresh handle resumes the trajectory."""
     orc, hip = _oracle_and_hip(1024, 16, po.CALC_DENSE_GAUSSIAN, po.F64, seed=21, steps=0)
