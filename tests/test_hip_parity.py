@@ -119,6 +119,16 @@ def test_hip_equals_oracle_fresh_cases(W, D, calc, dtype, steps, interval):
     _assert_same_state(orc, hip)
 
 
+def test_two_level_jump_table_with_non_power_of_two_half(monkeypatch):
+    monkeypatch.setenv("MCMCPP_HIP_TASK_TABLE_MB", "0")
+    orc, hip = _oracle_and_hip(1000, 9, po.CALC_ROSENBROCK, po.F64, seed=5, steps=0)
+    oc, oa = orc.run(40)
+    hc, ha = hip.run(40)
+    np.testing.assert_array_equal(hc, oc)
+    np.testing.assert_array_equal(ha, oa)
+    _assert_same_state(orc, hip)
+
+
 def test_seed_and_stream_are_honoured():
     for seed, stream in [(-7 & (2**64 - 1), 0), (2**40 + 1, 5)]:
         t = np.float64
@@ -185,8 +195,12 @@ def test_checkpoint_and_resume_in_a_new_handle():
 def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
     base = None
     for env in [{}, {"MCMCPP_HIP_PASSES": "1"}, {"MCMCPP_HIP_PASSES": "4"}, {"MCMCPP_HIP_PASSES": "16"},
-                {"MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"}]:
-        for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS"):
+                {"MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"},
+                {"MCMCPP_HIP_TASK_TABLE_MB": "0"},                         # two-level jump table (very large ensembles)
+                {"MCMCPP_HIP_TASK_TABLE_MB": "0", "MCMCPP_HIP_PASSES": "8"},
+                {"MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS": "0"}]:             # matrix-core kernel
+        for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS", "MCMCPP_HIP_TASK_TABLE_MB",
+                  "MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
