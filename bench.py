@@ -253,7 +253,7 @@ def main():
                        "slicing_interval": args.interval, "chains": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "stretch_half_step_kernel<double, DenseGaussianFn, EPL=2, LPW=16>",
+                         "kernel": "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16, P=2>",
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": us_per_launch,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "

@@ -57,7 +57,7 @@ struct GroupCtx
     int dims;       // D
     T* stage;       // wave-private LDS: 64*EPL elements, this lane's slice at [lane*EPL, lane*EPL+EPL)
     int lane;       // lane in wavefront
-    const T* block_scratch;  // block-shared LDS filled by Calc::block_init (nullptr when the calculator claims none)
+    const T* block_scratch;  // block-shared LDS filled by Calc::block_commit (nullptr when the calculator claims none)
     bool vec_ok;    // D is a whole number of 16-byte vectors
 
     __device__ __forceinline__ int first_index() const { return sub * EPL; }

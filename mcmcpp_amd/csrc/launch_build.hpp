@@ -18,12 +18,12 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
                        a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 
-template <class T, class Calc, int EPL, int LPW>
+template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (size_t)kWavesPerBlock * 16 * 33 * sizeof(T);
+    const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * 33) * sizeof(T);
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save);
-    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st,
+    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st,
                        a.draws, a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 
@@ -42,8 +42,8 @@ void put(LaunchTable<T>& t)
     t.half_step[LPWLOG][EPLSHIFT] = &launch_half<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     if constexpr (Calc::template MatrixCore<(kBase << EPLSHIFT), (1 << LPWLOG)>::kUse)
     {
-        t.half_step_mc[LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
-        t.mc_passes[LPWLOG][EPLSHIFT] = 4;
+        t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
+        t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
     }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
 }

@@ -12,7 +12,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430003u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430004u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -25,9 +25,8 @@ struct LaunchTable
     // [log2(LPW)][log2(EPL/base)]; nullptr where not built
     HalfStepFn half_step[kLpwLevels][kMaxEplShift];
     CalcFn calc[kLpwLevels][kMaxEplShift];
-    // matrix-core variant (nullptr where the calculator has none): needs even D and exactly mc_passes passes
-    HalfStepFn half_step_mc[kLpwLevels][kMaxEplShift];
-    int mc_passes[kLpwLevels][kMaxEplShift];
+    // matrix-core variants (nullptr where the calculator has none): need even D and exactly 2 ([0]) / 4 ([1]) passes
+    HalfStepFn half_step_mc[2][kLpwLevels][kMaxEplShift];
 };
 
 void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, hipStream_t stream);

@@ -9,6 +9,7 @@
 //   Walker[] (heap row per walker)  MCMCpp/Walker/Walker.h:142-149 -> pos[W][D], logp[W], n_accept[W] in HBM
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -222,7 +223,7 @@ public:
                         prop.gcnArchName);
         num_cus = prop.multiProcessorCount;
 
-        // walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then amortise phase A
+        // walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then amortise the per-walker draw computation
         const int wpp = 64 / lpw;
         long forced = env_long("MCMCPP_HIP_PASSES", 0);
         if (forced > 0)
@@ -235,15 +236,14 @@ public:
         }
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;
-        // Matrix-core variant of the half-step kernel (dense calculators, even D): 16 walkers per wavefront.  It
-        // needs a quarter of the wavefronts, so it only pays once the plain kernel would fill the chip several
-        // times over (measured: 16 384 walkers 6.0 vs 5.4 us per launch, 65 536 walkers 8.8 vs 12.0, 262 144
-        // walkers 28 vs 39 us).
-        const long mc_min = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 32768);
-        if (table->half_step_mc[lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
+        // Matrix-core variants of the half-step kernel (dense calculators, fp64, even D in 18..32): the wavefront's
+        // walkers are rows of one MFMA tile -- 8 walkers (2 passes) until the chip is full, 16 (4 passes) beyond.
+        const long mc_min = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
+        if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
         {
-            half_fn = table->half_step_mc[lpw_log][epl_shift];
-            passes = table->mc_passes[lpw_log][epl_shift];
+            const int big = shard_count >= env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768) ? 1 : 0;
+            half_fn = table->half_step_mc[big][lpw_log][epl_shift];
+            passes = big ? 4 : 2;
         }
 
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
@@ -375,6 +375,8 @@ public:
         last_ms = 0.0;
         last_launches = 0;
         if (total == 0) return MCMCPP_HIP_OK;
+        const bool dbg = env_long("MCMCPP_HIP_DEBUG_TIMING", 0) != 0;
+        const auto tp0 = std::chrono::steady_clock::now();
 
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
         int64_t sub_saved = n_saved;  // stored steps per sub-chunk
@@ -395,6 +397,7 @@ public:
         rc = ensure_graphs();
         if (rc) return rc;
 
+        const auto tp1 = std::chrono::steady_clock::now();
         const int64_t n_sub = (n_saved + sub_saved - 1) / sub_saved;
         double launch_ms = 0.0;  // GPU time of the half-step launches alone (downloads excluded)
         int64_t pending_first = -1, pending_count = 0;  // sub-chunk whose staging still has to reach chain_out
@@ -437,6 +440,7 @@ public:
                 pending_buf = buf;
             }
         }
+        const auto tp2 = std::chrono::steady_clock::now();
         if (rc == MCMCPP_HIP_OK)
         {
             if (pending_first >= 0)
@@ -458,10 +462,20 @@ public:
             if (accepted_per_step)
                 HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
         }
+        const auto tp3 = std::chrono::steady_clock::now();
         {
             // leave no pointer to run-scoped buffers in the device-side RunInfo
             const int rc2 = upload_idle_run_info();
             if (rc == MCMCPP_HIP_OK) rc = rc2;
+        }
+        if (dbg)
+        {
+            const auto tp4 = std::chrono::steady_clock::now();
+            auto us = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) {
+                return std::chrono::duration<double, std::micro>(y - x).count();
+            };
+            std::fprintf(stderr, "[mcmcpp_hip] run: setup %.0f us, enqueue %.0f us, drain %.0f us, idle-info %.0f us, gpu launches %.0f us\n",
+                         us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4), last_ms * 1e3);
         }
         return rc;
     }

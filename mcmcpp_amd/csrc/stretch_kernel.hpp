@@ -17,7 +17,8 @@
 //            these walkers needs at its NEXT update (two half-steps ahead: same colour, same wavefront) are
 //            computed now, in the shadow of the partner-row gather, and left in a 32-byte record per walker.
 //            The launch's dependent chain is then two memory round trips plus the calculator.
-// No MFMA: the work is element-wise plus a per-walker reduction.
+// No MFMA here: the work is element-wise plus a per-walker reduction (calculators with a dense product have a
+// matrix-core variant further down).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -556,17 +557,20 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
 // ---------------------------------------------------------------------------------------------------------
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
-template <class T, class Calc, int EPL, int LPW>
+// P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
+template <class T, class Calc, int EPL, int LPW, int P>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
-    constexpr int P = 4;        // passes: 4 lane groups x 4 passes = 16 walkers = one MFMA tile of rows
-    constexpr int N2 = 32;      // padded dimension
+    static_assert(P == 2 || P == 4, "two or four passes");
+    constexpr int NW = 4 * P;   // walkers per wavefront
     constexpr int XS = 33;      // row stride of the staged proposals (doubles): odd, to spread LDS banks
+    // LDS: [P^T zero-padded to 32 x 32 (workgroup)][proposal rows, NW x XS per wavefront]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (16 * XS);
+    T* sh_pt = reinterpret_cast<T*>(smem);
+    T* sh_x = sh_pt + 32 * 32 + (threadIdx.x >> 6) * (NW * XS);
 
     const HalfStepArgs<T>& a = rest;
 #ifdef MCMCPP_STAMPS
@@ -587,9 +591,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
 
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int first = wave * 16;
+    const int first = wave * NW;
     const bool wave_active = first < h_shard_count;
-    if (!wave_active) return;  // no workgroup-wide barrier in this kernel
     const int half_base = h_color ? h_n : 0;
     const int other_base = h_color ? 0 : h_n;
     const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
@@ -599,7 +602,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     const int i0c = col_ok ? i0 : 0;
     const int last_li = h_shard_count - 1;
 
-    // ---- first round trip: draw records, own rows, log-posteriors, counters of all four passes --------------
+    // ---- first round trip: draw records, own rows, log-posteriors, counters of all passes; the matrix ------------
     DrawRec<T> rec[P];
     T own[P][2];
     T lp_old[P];
@@ -610,7 +613,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     for (int q = 0; q < P; ++q)
     {
         const int li = first + 4 * q + grp;
-        active[q] = li < h_shard_count;
+        active[q] = wave_active && li < h_shard_count;
         w[q] = half_base + h_shard_begin + (active[q] ? li : 0);
         rec[q] = h_draws[w[q]];
         {
@@ -621,28 +624,13 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         lp_old[q] = h_logp[w[q]];
         nacc_old[q] = h_n_accept[w[q]];  // every lane of the group reads the same word: no divergent branch, no wait
     }
-    // B fragments of P^T (params hold P transposed, row j = P^T[j][.]): this lane's cell of every 4x16 block
-    T bfrag[2][8];
-    {
-        const T* pt = a.calc_params;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-        {
-            const int k = 4 * ks + grp;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-            {
-                const int nn = 16 * nt + sub;
-                const bool inside = k < h_dims && nn < h_dims;
-                const T v = pt[(size_t)(inside ? k : 0) * h_dims + (inside ? nn : 0)];
-                bfrag[nt][ks] = inside ? v : (T)0;
-            }
-        }
-    }
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);
+
     const StepCtl ctl = *hot_ctl_in;
     const RunInfo run = *a.run;
-    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;  // 48 of the 64 lanes compute the 16 walkers' next draws
-    const int i_a = h_shard_begin + min(first + slot_a, last_li);
+    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;  // 3*NW lanes compute the walkers' next draws
+    const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
     const bool direct_jump = a.task_jump != nullptr;
     Affine128 j_a, j_b;
     if (direct_jump)
@@ -653,7 +641,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         j_b = a.jump_lo[i_a & 255];
     }
 
-    // ---- second round trip: the partner rows of all four passes ------------------------------------------------
+    // ---- second round trip: the partner rows of all passes ----------------------------------------------------------
     T par[P][2];
 #pragma unroll
     for (int q = 0; q < P; ++q)
@@ -663,9 +651,11 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         par[q][0] = (active[q] && col_ok) ? v.x : (T)0;
         par[q][1] = (active[q] && col_ok) ? v.y : (T)0;
     }
-
     MCMCPP_STAMP(1);  // records landed, partner gather issued
-    // ---- in its shadow: hand-over to the next launch and the draws of these walkers' next update ----------------
+
+    // ---- in its shadow: the matrix goes to LDS, hand-over to the next launch, the walkers' next draws ----------------
+    Calc::block_commit(calc_pf, sh_pt, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);
+    __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x == 0)
     {
         StepCtl nx = ctl;
@@ -682,15 +672,16 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         }
         *a.ctl_out = nx;
     }
+    if (!wave_active) return;
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
         save_slot = a.direct_save_slot;
     else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
-    if (lane < 48 && first + slot_a < h_shard_count)
+    if (lane < 3 * NW && first + slot_a < h_shard_count)
         compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws + half_base + h_shard_begin + first + slot_a);
-
     MCMCPP_STAMP(2);  // next draws done
+
     // ---- proposals (StretchMove.h:105-108), staged as rows of X ---------------------------------------------------
     T prop[P][2];
 #pragma unroll
@@ -710,16 +701,18 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
     MCMCPP_STAMP(3);  // partner rows landed, proposals staged
+
     // ---- Y = X * P^T on the matrix cores: 8 k-steps x 2 column tiles, k ascending (the host's fma order) ------------
     mfma_f64x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
     {
-        const double xa = sh_x[sub * XS + 4 * ks + grp];  // A[m = lane%16][k = 4ks + lane/16]
-        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bfrag[0][ks], y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bfrag[1][ks], y1, 0, 0, 0);
+        const double xa = (sub < NW) ? sh_x[sub * XS + 4 * ks + grp] : 0.0;  // A[m = lane%16][k = 4ks + lane/16]
+        const double b0 = sh_pt[(4 * ks + grp) * 32 + sub];                  // B[k = 4ks + lane/16][n = lane%16]
+        const double b1 = sh_pt[(4 * ks + grp) * 32 + 16 + sub];
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b0, y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b1, y1, 0, 0, 0);
     }
     // t[m][n] = x[m][n] * y[m][n], then the canonical tree over n: tree16(columns 0..15) + tree16(columns 16..31)
     T lp_new[P];
@@ -740,8 +733,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         t1 = t1 + dpp_move<0x140>(t1);
         lp_new[r] = (T)-0.5 * (t0 + t1);
     }
-
     MCMCPP_STAMP(4);  // calculator done
+
     // ---- Metropolis accept in place, chain store, counters ------------------------------------------------------------
     unsigned accepted_here = 0;
 #pragma unroll
