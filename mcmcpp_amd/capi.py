@@ -136,8 +136,12 @@ class HipSampler:
     def seek(self, ensemble_steps_done):
         self._check(lib().mcmcpp_hip_seek(self.h, ensemble_steps_done))
 
-    def run(self, n_saved, interval=1, save_chain=True, want_accepted=True):
-        chain = np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None
+    def run(self, n_saved, interval=1, save_chain=True, want_accepted=True, out=None):
+        """out: optional preallocated (n_saved, W, D) array receiving the stored steps (like a Chain block that
+        already exists); by default a fresh array is allocated."""
+        if out is not None:
+            assert save_chain and out.shape == (n_saved, self.W, self.D) and out.dtype == self.np_t and out.flags.c_contiguous
+        chain = out if out is not None else (np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None)
         acc = np.zeros(n_saved * interval, dtype=np.uint32) if want_accepted else None
         self._check(lib().mcmcpp_hip_run(self.h, n_saved, interval, _ptr(chain), _ptr(acc)))
         return chain, acc

@@ -383,8 +383,8 @@ public:
         if (chain_out)
         {
             sub_saved = (int64_t)(chain_subchunk_bytes / step_bytes);
-            const int64_t quarter = (n_saved + 3) / 4;  // keep the last (un-overlappable) host copy short
-            if (sub_saved > quarter) sub_saved = quarter;
+            const int64_t eighth = (n_saved + 7) / 8;  // keep the last (un-overlappable) host copy short
+            if (sub_saved > eighth) sub_saved = eighth;
             if (sub_saved < 1) sub_saved = 1;
         }
         int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, chain_out ? step_bytes * (size_t)sub_saved : 0);
