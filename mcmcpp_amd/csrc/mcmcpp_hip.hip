@@ -250,11 +250,13 @@ public:
         {
             stream = (hipStream_t)c.hip_stream;  // may be the null (legacy default) stream
             own_stream = false;
+            stream_valid = true;
         }
         else
         {
             HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
             own_stream = true;
+            stream_valid = true;
         }
         for (int k = 0; k < 4; ++k)
         {
@@ -814,6 +816,7 @@ private:
     void release()
     {
         if (device >= 0) hipSetDevice(device);
+        if (stream_valid) hipStreamSynchronize(stream);  // half_step_async work may still be in flight
         for (hipGraphExec_t ex : graph_cache)
             if (ex) hipGraphExecDestroy(ex);
         if (own_pos && d_pos) hipFree(d_pos);
@@ -856,7 +859,7 @@ private:
     void* h_stage[2] = {nullptr, nullptr};
     uint32_t* d_acc = nullptr;
     hipStream_t stream = nullptr;
-    bool own_stream = false, own_pos = false, have_state = false;
+    bool own_stream = false, own_pos = false, have_state = false, stream_valid = false;
     hipEvent_t ev_t0[4] = {nullptr, nullptr, nullptr, nullptr}, ev_t1[4] = {nullptr, nullptr, nullptr, nullptr};
     T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr;
     uint32_t* d_nacc = nullptr;
