@@ -3,8 +3,8 @@
 // ParallelEnsembleSampler + StretchMove, linked against libmcmcpp_hip.so instead.
 //
 //   facade_parity <fixture.bin>
-// fixture: int32 W, D, steps, slicing, calc, nparams, nkept; double params[nparams]; double pos[W*D];
-//          double logp[W]; int32 kept_step[nkept]; double kept[nkept][W*D]; uint64 accepted_total, total_steps
+// fixture: int32 W, D, steps, slicing, calc, nparams, nkept, dtype (0 = double, 1 = float); T params[nparams];
+//          T pos[W*D]; T logp[W]; int32 kept_step[nkept]; T kept[nkept][W*D]; uint64 accepted_total, total_steps
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -29,25 +29,41 @@ static int failures = 0;
         }                                                               \
     } while (0)
 
+template <class T>
 struct Fixture
 {
     int W, D, steps, slicing, calc, nparams, nkept;
-    std::vector<double> params, pos, logp, kept;
+    std::vector<T> params, pos, logp, kept;
     std::vector<int> keptStep;
     unsigned long long acceptedTotal, totalSteps;
 };
 
-static Fixture load(const char* path)
+static int peekDtype(const char* path)
 {
-    Fixture f;
     FILE* fp = std::fopen(path, "rb");
     if (!fp)
     {
         std::perror(path);
         std::exit(2);
     }
-    int hdr[7];
-    if (std::fread(hdr, sizeof(int), 7, fp) != 7) std::exit(2);
+    int hdr[8];
+    if (std::fread(hdr, sizeof(int), 8, fp) != 8) std::exit(2);
+    std::fclose(fp);
+    return hdr[7];
+}
+
+template <class T>
+static Fixture<T> load(const char* path)
+{
+    Fixture<T> f;
+    FILE* fp = std::fopen(path, "rb");
+    if (!fp)
+    {
+        std::perror(path);
+        std::exit(2);
+    }
+    int hdr[8];
+    if (std::fread(hdr, sizeof(int), 8, fp) != 8) std::exit(2);
     f.W = hdr[0], f.D = hdr[1], f.steps = hdr[2], f.slicing = hdr[3], f.calc = hdr[4], f.nparams = hdr[5], f.nkept = hdr[6];
     f.params.resize(f.nparams);
     f.pos.resize((size_t)f.W * f.D);
@@ -55,11 +71,11 @@ static Fixture load(const char* path)
     f.keptStep.resize(f.nkept);
     f.kept.resize((size_t)f.nkept * f.W * f.D);
     size_t ok = 1;
-    if (f.nparams) ok &= std::fread(f.params.data(), 8, f.nparams, fp) == (size_t)f.nparams;
-    ok &= std::fread(f.pos.data(), 8, f.pos.size(), fp) == f.pos.size();
-    ok &= std::fread(f.logp.data(), 8, f.logp.size(), fp) == f.logp.size();
+    if (f.nparams) ok &= std::fread(f.params.data(), sizeof(T), f.nparams, fp) == (size_t)f.nparams;
+    ok &= std::fread(f.pos.data(), sizeof(T), f.pos.size(), fp) == f.pos.size();
+    ok &= std::fread(f.logp.data(), sizeof(T), f.logp.size(), fp) == f.logp.size();
     ok &= std::fread(f.keptStep.data(), 4, f.nkept, fp) == (size_t)f.nkept;
-    ok &= std::fread(f.kept.data(), 8, f.kept.size(), fp) == f.kept.size();
+    ok &= std::fread(f.kept.data(), sizeof(T), f.kept.size(), fp) == f.kept.size();
     ok &= std::fread(&f.acceptedTotal, 8, 1, fp) == 1;
     ok &= std::fread(&f.totalSteps, 8, 1, fp) == 1;
     std::fclose(fp);
@@ -68,48 +84,49 @@ static Fixture load(const char* path)
 }
 
 // a PostStepAction (reference concept: Utility/NoAction.h) that counts its calls and looks at the chain
+template <class T>
 struct CountingAction
 {
     long calls = 0;
     long lastSeenSteps = 0;
-    void performAction(const Chain::ChainStepIterator<double>& start, const Chain::ChainStepIterator<double>& end)
+    void performAction(const Chain::ChainStepIterator<T>& start, const Chain::ChainStepIterator<T>& end)
     {
         ++calls;
         lastSeenSteps = end.stepIndex() - start.stepIndex();
     }
 };
 
-template <class Sampler>
-static void checkChain(Sampler& s, const Fixture& f)
+template <class Sampler, class T>
+static void checkChain(Sampler& s, const Fixture<T>& f)
 {
     CHECK(s.getStoredSteps() == f.steps + 1);
     // step 0 is the initial placement
     auto it = s.getStepIttBegin();
-    CHECK(std::memcmp(*it, f.pos.data(), sizeof(double) * f.pos.size()) == 0);
+    CHECK(std::memcmp(*it, f.pos.data(), sizeof(T) * f.pos.size()) == 0);
     for (int k = 0; k < f.nkept; ++k)
     {
         auto jt = s.getStepIttBegin();
         jt += f.keptStep[k];
-        CHECK(std::memcmp(*jt, f.kept.data() + (size_t)k * f.W * f.D, sizeof(double) * f.W * f.D) == 0);
+        CHECK(std::memcmp(*jt, f.kept.data() + (size_t)k * f.W * f.D, sizeof(T) * f.W * f.D) == 0);
     }
     // the parameter-set view walks the same memory walker by walker
     auto pit = s.getParamSetIttBegin();
-    for (int w = 0; w < f.W; ++w, ++pit) CHECK(std::memcmp(*pit, f.pos.data() + (size_t)w * f.D, sizeof(double) * f.D) == 0);
+    for (int w = 0; w < f.W; ++w, ++pit) CHECK(std::memcmp(*pit, f.pos.data() + (size_t)w * f.D, sizeof(T) * f.D) == 0);
     long sets = 0;
     for (auto p = s.getParamSetIttBegin(); p != s.getParamSetIttEnd(); ++p) ++sets;
     CHECK(sets == (long)(f.steps + 1) * f.W);
 }
 
-template <class Calc>
-static void runCase(const Fixture& f, Calc calc)
+template <class T, class Calc>
+static void runCase(const Fixture<T>& f, Calc calc)
 {
-    typedef Mover::StretchMove<double, Calc> MoverType;
-    std::vector<double> pos(f.pos), logp(f.logp);
+    typedef Mover::StretchMove<T, Calc> MoverType;
+    std::vector<T> pos(f.pos), logp(f.logp);
     // the initial auxValues are what user code computes with the Calculator (reference test main.cpp:141-205)
     for (int w = 0; w < f.W; ++w) CHECK(calc.calcLogPostProb(pos.data() + (size_t)w * f.D) == f.logp[w]);
     {
         MoverType mover(f.D, 0, calc);
-        EnsembleSampler<double, MoverType> sampler(0, f.W, f.D, mover);
+        EnsembleSampler<T, MoverType> sampler(0, f.W, f.D, mover);
         if (f.slicing > 1) sampler.setSlicingMode(true, f.slicing);
         sampler.setInitialWalkerPos(pos.data(), logp.data());
         CHECK(sampler.runMCMC(f.steps / 2));
@@ -117,18 +134,18 @@ static void runCase(const Fixture& f, Calc calc)
         checkChain(sampler, f);
         CHECK(sampler.getAcceptedSteps() == f.acceptedTotal);
         CHECK(sampler.getTotalSteps() == f.totalSteps);
-        CHECK(sampler.getAcceptanceFraction() == (double)f.acceptedTotal / (double)f.totalSteps);
+        CHECK(sampler.getAcceptanceFraction() == (T)f.acceptedTotal / (T)f.totalSteps);
         std::uint64_t ties = 1, redraws = 1;
         sampler.diagnostics(&ties, &redraws);
         CHECK(ties == 0 && redraws == 0);
         // reset keeps the walkers, forgets chain and counters (EnsembleSampler.h:312-322)
-        std::vector<double> now((size_t)f.W * f.D);
+        std::vector<T> now((size_t)f.W * f.D);
         sampler.currentState(now.data(), nullptr, nullptr);
         sampler.reset();
         CHECK(sampler.getStoredSteps() == 0 && sampler.getAcceptedSteps() == 0);
         sampler.storeCurrentWalkerPositions();
         CHECK(sampler.getStoredSteps() == 1);
-        CHECK(std::memcmp(*sampler.getStepIttBegin(), now.data(), sizeof(double) * now.size()) == 0);
+        CHECK(std::memcmp(*sampler.getStepIttBegin(), now.data(), sizeof(T) * now.size()) == 0);
         CHECK(sampler.runMCMC(3));
         CHECK(sampler.getTotalSteps() == (unsigned long long)f.W * 3 * (f.slicing > 1 ? f.slicing : 1));
         sampler.sliceAndBurnChain(2, 1);
@@ -137,26 +154,44 @@ static void runCase(const Fixture& f, Calc calc)
     {
         // the parallel facade follows the same (sequential, reproducible) trajectory
         MoverType mover(f.D, 0, calc);
-        CountingAction action;
-        ParallelEnsembleSampler<double, MoverType, CountingAction> sampler(0, 8, f.W, f.D, mover, 2147483648ULL, &action);
+        CountingAction<T> action;
+        ParallelEnsembleSampler<T, MoverType, CountingAction<T> > sampler(0, 8, f.W, f.D, mover, 2147483648ULL, &action);
         sampler.setSamplingMode(f.slicing, 0);
         sampler.setInitialWalkerPos(pos.data(), logp.data());
         CHECK(sampler.runMCMC(f.steps));
         checkChain(sampler, f);
         CHECK(sampler.getAcceptedSteps() == f.acceptedTotal);
-        CHECK(sampler.getAcceptanceFraction() == (double)f.acceptedTotal / (double)f.totalSteps);
+        CHECK(sampler.getAcceptanceFraction() == (T)f.acceptedTotal / (T)f.totalSteps);
         CHECK(action.calls == (long)f.steps * f.slicing);  // once per ensemble step (EnsembleSampler.h:356-359)
         CHECK(action.lastSeenSteps == f.steps + 1);
     }
     {
         // chain budget: room for 5 steps only -> runMCMC reports false when it fills (EnsembleSampler.h:293)
         MoverType mover(f.D, 0, calc);
-        EnsembleSampler<double, MoverType> sampler(0, f.W, f.D, mover, 5ULL * f.W * f.D * sizeof(double));
+        EnsembleSampler<T, MoverType> sampler(0, f.W, f.D, mover, 5ULL * f.W * f.D * sizeof(T));
         sampler.setInitialWalkerPos(pos.data(), logp.data());
         CHECK(sampler.runMCMC(3));
         CHECK(!sampler.runMCMC(10));
         CHECK(sampler.getStoredSteps() == 5);
     }
+}
+
+template <class T>
+static int runFixture(const char* path)
+{
+    const Fixture<T> f = load<T>(path);
+    switch (f.calc)
+    {
+    case Device::IsoGaussianId: runCase<T>(f, Device::IsoGaussian<T>(f.D)); break;
+    case Device::DenseGaussianId: runCase<T>(f, Device::DenseGaussian<T>(f.D, f.params.data())); break;
+    case Device::RosenbrockId: runCase<T>(f, Device::Rosenbrock<T>(f.D, f.params[0], f.params[1], f.params[2])); break;
+    case Device::SkewedGaussian2DId: runCase<T>(f, Device::SkewedGaussian2D<T>(f.params[0])); break;
+    default: std::printf("unknown calculator %d\n", f.calc); return 2;
+    }
+    if (failures == 0)
+        std::printf("facade_parity OK (%d walkers x %d params, %d stored steps, slicing %d, %s)\n", f.W, f.D, f.steps, f.slicing,
+                    sizeof(T) == 8 ? "double" : "float");
+    return failures == 0 ? 0 : 1;
 }
 
 int main(int argc, char** argv)
@@ -166,15 +201,5 @@ int main(int argc, char** argv)
         std::printf("usage: facade_parity fixture.bin\n");
         return 2;
     }
-    const Fixture f = load(argv[1]);
-    switch (f.calc)
-    {
-    case Device::IsoGaussianId: runCase(f, Device::IsoGaussian<double>(f.D)); break;
-    case Device::DenseGaussianId: runCase(f, Device::DenseGaussian<double>(f.D, f.params.data())); break;
-    case Device::RosenbrockId: runCase(f, Device::Rosenbrock<double>(f.D, f.params[0], f.params[1], f.params[2])); break;
-    case Device::SkewedGaussian2DId: runCase(f, Device::SkewedGaussian2D<double>(f.params[0])); break;
-    default: std::printf("unknown calculator %d\n", f.calc); return 2;
-    }
-    if (failures == 0) std::printf("facade_parity OK (%d walkers x %d params, %d stored steps, slicing %d)\n", f.W, f.D, f.steps, f.slicing);
-    return failures == 0 ? 0 : 1;
+    return peekDtype(argv[1]) == 0 ? runFixture<double>(argv[1]) : runFixture<float>(argv[1]);
 }

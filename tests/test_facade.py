@@ -19,8 +19,9 @@ LINK = ["-L" + os.path.join(ROOT, "mcmcpp_amd"), "-lmcmcpp_hip", "-Wl,-rpath," +
 def _compile(src, out, link):
     os.makedirs(BUILD, exist_ok=True)
     exe = os.path.join(BUILD, out)
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(
-            os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs):
+    newest = max([os.path.getmtime(src)] + [os.path.getmtime(os.path.join(dp, f))
+                                            for dp, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs])
+    if not os.path.exists(exe) or os.path.getmtime(exe) < newest:
         capi.build_library()
         cmd = ["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror"] + INC + [src, "-o", exe] + (LINK if link else [])
         subprocess.check_call(cmd)
@@ -51,19 +52,20 @@ def _write_fixture(g, path):
     kept = [k for k in g.full_steps]
     with open(path, "wb") as f:
         npar = 0 if g.params is None else g.params.size
-        f.write(struct.pack("7i", g.W, g.D, g.steps, g.slicing, g.calc, npar, len(kept)))
+        f.write(struct.pack("8i", g.W, g.D, g.steps, g.slicing, g.calc, npar, len(kept), g.dtype))
         if npar:
-            f.write(np.asarray(g.params, dtype=np.float64).tobytes())
-        f.write(np.asarray(g.init_pos, dtype=np.float64).tobytes())
-        f.write(np.asarray(g.init_logp, dtype=np.float64).tobytes())
+            f.write(np.asarray(g.params, dtype=g.np_t).tobytes())
+        f.write(np.asarray(g.init_pos, dtype=g.np_t).tobytes())
+        f.write(np.asarray(g.init_logp, dtype=g.np_t).tobytes())
         f.write(np.asarray(kept, dtype=np.int32).tobytes())
         for k in kept:
-            f.write(np.asarray(g.z["chain_step_%d" % k], dtype=np.float64).tobytes())
+            f.write(np.asarray(g.z["chain_step_%d" % k], dtype=g.np_t).tobytes())
         f.write(struct.pack("2Q", g.accepted_total, g.total_steps))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["iso64x4", "iso100x7", "dense96x16", "rosen80x8", "skewed320x2"])
+@pytest.mark.parametrize("name", ["iso64x4", "iso100x7", "dense96x16", "rosen80x8", "skewed320x2", "iso64x4_f32",
+                                  "dense80x5_f32"])
 def test_facade_matches_reference_golden(name, tmp_path):
     exe = _compile(os.path.join(ROOT, "tests", "cpp", "facade_parity.cpp"), "facade_parity", link=True)
     fx = tmp_path / (name + ".bin")

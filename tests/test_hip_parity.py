@@ -259,6 +259,19 @@ def test_config5_shape_single_gpu_against_oracle():
     _assert_same_state(orc, hip)
 
 
+def test_million_walker_ensemble_and_empty_run():
+    """Maximum sizes: 2^20 + 2 walkers (two-level jump table, ragged last wavefront) for two steps against the
+    multi-threaded oracle; and the empty request (0 stored steps) is a no-op."""
+    orc, hip = _oracle_and_hip(2**20 + 2, 8, po.CALC_ISO_GAUSSIAN, po.F64, seed=4, steps=0, salt=0)
+    chain, acc = hip.run(0)
+    assert chain.shape[0] == 0 and acc.size == 0 and hip.counters()["ensemble_steps"] == 0
+    oc, oa = orc.run(2, mode=po.MODE_COUNTER, threads=8)
+    hc, ha = hip.run(2)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip)
+
+
 def test_config2_statistical_properties_long_run():
     """16 384 x 32 correlated Gaussian (BASELINE config 2), 600 steps: size-independent checks --
     acceptance in the stretch-move range for D = 32, and the sample covariance of the last stored steps
