@@ -35,18 +35,13 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def ar1_precision(D, rho):
-    P = np.zeros((D, D))
-    d = 1.0 - rho * rho
-    for i in range(D):
-        P[i, i] = (1.0 if i in (0, D - 1) else 1.0 + rho * rho) / d
-        if i + 1 < D:
-            P[i, i + 1] = P[i + 1, i] = -rho / d
-    return P
+    from mcmcpp_amd import workloads
+    return workloads.ar1_precision(D, rho)
 
 
 def cpu_baseline(W, D, P, sample_steps):
-    """Time the CPU path on a bounded sample of the workload.  oracle/ is used here only as the measured
-    baseline, never by the GPU path."""
+    """Time the CPU path on a bounded sample of the workload.  oracle/ is imported here and only here: as the
+    measured baseline, never by the GPU path."""
     from oracle import pyoracle as po
     # the GPU box gives one GPU job a share of 16 host cores (gpurun notes); more threads only thrash
     cores = min(len(os.sched_getaffinity(0)) or 1, 16)
@@ -78,9 +73,10 @@ def cpu_baseline(W, D, P, sample_steps):
     return out
 
 
-def bench_split(args, rank, local_rank, world, dist, torch, capi, po):
+def bench_split(args, rank, local_rank, world, dist, torch, capi):
     """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling."""
     from mcmcpp_amd import distributed as md
+    from mcmcpp_amd import workloads
     if dist is None:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,7 +86,7 @@ def bench_split(args, rank, local_rank, world, dist, torch, capi, po):
     steps_per = 50
     dev = "cuda:%d" % local_rank
     ens = md.SplitEnsemble(W, D, lambda b, c: md.HipShardBackend(W, D, capi.CALC_ISO_GAUSSIAN, None, 0, 0, capi.F64, b, c, dev))
-    pos = po.init_positions(po.F64, W, D, salt=0)
+    pos = workloads.init_positions(W, D, salt=0)
     logp = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank).calc_logp(pos)
     ens.set_state(pos, logp)
     for _ in range(args.warmup):
@@ -171,11 +167,10 @@ def main():
             dist.init_process_group(backend)
     reduce_device = "cuda" if backend == "nccl" else "cpu"
 
-    from mcmcpp_amd import capi
-    from oracle import pyoracle as po  # initial positions only (pure integer-hash recipe)
+    from mcmcpp_amd import capi, workloads
 
     if args.mode == "split":
-        return bench_split(args, rank, local_rank, world, dist, torch, capi, po)
+        return bench_split(args, rank, local_rank, world, dist, torch, capi)
 
     W, D = args.walkers, args.dims
     assert args.batch % args.interval == 0
@@ -184,7 +179,7 @@ def main():
     calc_id, calc_params = {"dense": (capi.CALC_DENSE_GAUSSIAN, P.ravel()), "iso": (capi.CALC_ISO_GAUSSIAN, None),
                             "rosenbrock": (capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05])}[args.calc]
     sampler = capi.HipSampler(W, D, calc_id, calc_params, seed=rank, device=local_rank)
-    pos = po.init_positions(po.F64, W, D, salt=rank)
+    pos = workloads.init_positions(W, D, salt=rank)
     sampler.set_state(pos, sampler.calc_logp(pos))
 
     # the stored steps land in host memory that already exists, like a block of the facade's Chain (allocated

@@ -6,15 +6,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["MCMCPP_HIP_LIB"] = os.path.join(ROOT, "mcmcpp_amd", "libmcmcpp_hip_stamps.so")
 sys.path.insert(0, ROOT)
 from mcmcpp_amd import capi
-from oracle import pyoracle as po
-import bench
+from mcmcpp_amd import workloads
 names = ["entry->partner gather issued", "tables+next draws", "wait partner rows", "calculator", "accept+stores issued"]
 for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
     D = 32
-    P = bench.ar1_precision(D, 0.5)
+    P = workloads.ar1_precision(D, 0.5)
     cid, prm = {"dense": (capi.CALC_DENSE_GAUSSIAN, P.ravel()), "iso": (capi.CALC_ISO_GAUSSIAN, None)}[calc]
     s = capi.HipSampler(W, D, cid, prm, seed=0)
-    pos = po.init_positions(po.F64, W, D)
+    pos = workloads.init_positions(W, D)
     s.set_state(pos, s.calc_logp(pos))
     acc = []
     for rep in range(20):
