@@ -39,6 +39,21 @@ def ar1_precision(D, rho):
     return workloads.ar1_precision(D, rho)
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when its first communicator comes up; the driver reads ONE JSON line
+    from stdout, so the process group is brought up with file descriptor 1 pointed at stderr."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cpu_baseline(W, D, P, sample_steps):
     """Time the CPU path on a bounded sample of the workload.  oracle/ is imported here and only here: as the
     measured baseline, never by the GPU path."""
@@ -81,7 +96,9 @@ def bench_split(args, rank, local_rank, world, dist, torch, capi):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
     W, D = 131072, 64
     steps_per = 50
     dev = "cuda:%d" % local_rank
@@ -161,10 +178,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        with _StdoutToStderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+            dist.barrier()  # brings the communicator up now
     reduce_device = "cuda" if backend == "nccl" else "cpu"
 
     from mcmcpp_amd import capi, workloads
