@@ -17,8 +17,12 @@ namespace MCMC
 {
 namespace Device
 {
+/// Element types the kernels are built for (the reference also admits long double; gfx950 has no such type).
 template <class ParamType>
-struct HipDtype;
+struct HipDtype
+{
+    static_assert(sizeof(ParamType) == 0, "the MI355X samplers run with ParamType = double or float");
+};
 template <>
 struct HipDtype<double>
 {
