@@ -281,8 +281,8 @@ public:
         HIP_TRY(hipMalloc(&d_ctl, sizeof(StepCtl) * 2));
         HIP_TRY(hipMalloc(&d_run, sizeof(RunInfo)));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
-        HIP_TRY(hipMalloc(&d_draws, sizeof(DrawRec<T>) * (size_t)W));
-        HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W));
+        HIP_TRY(hipMalloc(&d_draws, sizeof(DrawRec<T>) * (size_t)W * 2));  // two buffers: see HalfStepArgs::draws
+        HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2));
 #ifdef MCMCPP_STAMPS
         HIP_TRY(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d_stamps, 0, 8 * sizeof(unsigned long long)));
@@ -394,6 +394,7 @@ public:
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
+        enq_step = half_steps >> 1;
         args_red = make_args(0);
         args_blk = make_args(1);
         rc = ensure_graphs();
@@ -568,7 +569,7 @@ public:
         if (save_slot >= 0 && (!bound_chain || save_slot >= bound_slots))
             return fail(MCMCPP_HIP_E_ARG, "half_step_async: save_slot outside the bound device chain");
         HIP_TRY(hipSetDevice(device));
-        HalfStepArgs<T> a = make_args(color);
+        HalfStepArgs<T> a = make_args(color, (int)((half_steps >> 1) & 1));
         a.use_ctl_save = 0;
         a.partials = nullptr;
         a.direct_save_slot = save_slot;
@@ -640,6 +641,13 @@ private:
         return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     }
 
+    HalfStepArgs<T> make_args(int color, int parity) const
+    {
+        HalfStepArgs<T> a = make_args(color);
+        a.draw_parity = parity;
+        return a;
+    }
+
     HalfStepArgs<T> make_args(int color) const
     {
         HalfStepArgs<T> a;
@@ -682,6 +690,9 @@ private:
         a.direct_save_slot = -1;
         a.use_ctl_save = 1;
         a.stamps = d_stamps;
+        a.draw_parity = 0;
+        // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
+        a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
         return a;
     }
 
@@ -700,37 +711,42 @@ private:
         c->partial_slot = 0;
         HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
         // the draw records of the next red and the next black half-step (afterwards the launches keep them going)
-        launch_fill_draws(make_args(0), c->state, stream);
-        launch_fill_draws(make_args(1), state1, stream);
+        const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
+        launch_fill_draws(make_args(0, parity), c->state, stream);
+        launch_fill_draws(make_args(1, parity), state1, stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MCMCPP_HIP_OK;
     }
 
-    void enqueue_step()
+    void enqueue_step(int parity)
     {
+        args_red.draw_parity = parity;
+        args_blk.draw_parity = parity;
         half_fn(args_red, grid_blocks(), stream);
         half_fn(args_blk, grid_blocks(), stream);
     }
 
     // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
     // graph_steps for the bulk, one graph per distinct remainder)
-    int graph_for(int steps, hipGraphExec_t* out)
+    // (the record-buffer parity of every node is frozen into the graph, hence one graph per starting parity)
+    int graph_for(int steps, int start_parity, hipGraphExec_t* out)
     {
-        if ((int)graph_cache.size() <= steps) graph_cache.resize((size_t)steps + 1, nullptr);
-        if (!graph_cache[steps])
+        const size_t key = (size_t)steps * 2 + (size_t)start_parity;
+        if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
+        if (!graph_cache[key])
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            for (int s = 0; s < steps; ++s) enqueue_step();
+            for (int s = 0; s < steps; ++s) enqueue_step((start_parity + s) & 1);
             launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, d_ctl, d_run, stream);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
             HIP_TRY(hipGraphDestroy(g));
-            graph_cache[steps] = ex;
+            graph_cache[key] = ex;
         }
-        *out = graph_cache[steps];
+        *out = graph_cache[key];
         return MCMCPP_HIP_OK;
     }
 
@@ -738,35 +754,40 @@ private:
     {
         if (graph_steps < 1) return MCMCPP_HIP_OK;
         hipGraphExec_t ex;
-        return graph_for(graph_steps, &ex);
+        return graph_for(graph_steps, (int)(enq_step & 1), &ex);
     }
 
     // enqueue `steps` ensemble steps on the launch stream (graph replays, or plain launches when graphs are off)
     int enqueue_steps(int64_t steps)
     {
+        // enq_step: ensemble steps enqueued since set_state/seek (its low bit selects the record buffer)
         int64_t left = steps;
         if (graph_steps >= 1)
         {
             hipGraphExec_t ex = nullptr;
-            if (left >= graph_steps)
+            while (left >= graph_steps)
             {
-                int rc = graph_for(graph_steps, &ex);
+                int rc = graph_for(graph_steps, (int)(enq_step & 1), &ex);
                 if (rc) return rc;
-                for (; left >= graph_steps; left -= graph_steps) HIP_TRY(hipGraphLaunch(ex, stream));
+                HIP_TRY(hipGraphLaunch(ex, stream));
+                left -= graph_steps;
+                enq_step += (uint64_t)graph_steps;
             }
             if (left > 0)
             {
-                int rc = graph_for((int)left, &ex);  // one replay for the remainder
+                int rc = graph_for((int)left, (int)(enq_step & 1), &ex);  // one replay for the remainder
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
+                enq_step += (uint64_t)left;
             }
         }
         else
         {
             for (; left > 0; --left)
             {
-                enqueue_step();
+                enqueue_step((int)(enq_step & 1));
                 launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, d_ctl, d_run, stream);
+                enq_step += 1;
             }
             HIP_TRY(hipGetLastError());
         }
@@ -876,7 +897,7 @@ private:
     Affine128 half_jump;
     HalfStepArgs<T> args_red, args_blk;
     std::vector<hipGraphExec_t> graph_cache;  // [steps] -> instantiated graph
-    uint64_t half_steps = 0, steps_since_reset = 0;
+    uint64_t half_steps = 0, steps_since_reset = 0, enq_step = 0;
     double last_ms = 0.0;
     int64_t last_launches = 0;
     void* bound_chain = nullptr;

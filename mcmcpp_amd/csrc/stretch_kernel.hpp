@@ -85,7 +85,8 @@ struct HalfStepArgs
     const Affine128* jump_hi; // [ceil(n/256)] map of 3*256*m draws
     const Affine128* task_jump; // [3n] map of t+1 draws (base state -> state behind draw t), or nullptr for large n
     const T* calc_params;
-    DrawRec<T>* draws;        // [2][n] records of the next update of every walker (colour-major)
+    DrawRec<T>* draws;        // [2 buffers][2 colours][n] records of the coming updates: the update of ensemble step s
+                              // reads buffer s&1 and the draws for step s+1 are written to the other one
     Affine128 half_jump;      // map of 3*n draws: this half-step's base state -> the next one's
     Affine128 draw_jump[3];   // maps of 1, 2, 3 draws: a walker's base state -> the state behind draw k
     U128 inc;                 // pcg stream increment
@@ -107,6 +108,8 @@ struct HalfStepArgs
     unsigned long long* stamps; // diagnostic build only (MCMCPP_STAMPS): 8 shader-clock stamps of wavefront 0
     long long direct_save_slot; // >= 0: store into run->chain at this slot regardless of interval (sharded driver)
     int use_ctl_save;           // 1: saving follows RunInfo.interval / StepCtl.step_in_run
+    int draw_parity;            // ensemble step & 1: which record buffer this launch reads
+    int draw_wave;              // 1: the workgroup carries one extra wavefront that computes the next draws
 };
 
 template <class T, int EPL>
@@ -256,29 +259,81 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
 // everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
 struct HotBits
 {
-    static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save)
+    static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save,
+                                             int draw_parity, int draw_wave)
     {
         return (uint32_t)dims | ((uint32_t)passes << 12) | ((uint32_t)color << 20) | ((uint32_t)vec_ok << 21) |
-               ((uint32_t)n_is_pow2 << 22) | ((uint32_t)use_ctl_save << 23);
+               ((uint32_t)n_is_pow2 << 22) | ((uint32_t)use_ctl_save << 23) | ((uint32_t)draw_parity << 24) |
+               ((uint32_t)draw_wave << 25);
     }
 };
 
+// Hands the random stream and the step counters to the next half-step launch (one lane of the whole grid).
+template <class T>
+__device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCtl& ctl, const RunInfo& run, int color)
+{
+    StepCtl nx = ctl;
+    nx.state = apply(a.half_jump, ctl.state);
+    nx.state2 = apply(a.half_jump, ctl.state2);
+    nx.half_step = ctl.half_step + 1;
+    if (color)
+    {
+        // the ensemble step ends with the black half: advance the per-step counters
+        const bool saved = ctl.save_phase + 1u == (uint32_t)run.interval;
+        nx.step_in_run = ctl.step_in_run + 1;
+        nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
+        nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
+        nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
+    }
+    *a.ctl_out = nx;
+}
+
+// Body of the workgroup's extra wavefront (when HalfStepArgs::draw_wave): the next draws of all walkers the
+// workgroup updates, `group_walkers` of them starting at `group_first` (relative to the shard).  It runs beside
+// the updating wavefronts, so the draw arithmetic is on nobody's critical path.
+template <class T>
+__device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const StepCtl& ctl, DrawRec<T>* write_base, int shard_begin,
+                                               int shard_count, int group_first, int group_walkers, int lane)
+{
+    const bool direct = a.task_jump != nullptr;
+    const int tasks = 3 * group_walkers;
+    for (int t = lane; t < tasks; t += 64)
+    {
+        const int slot = t / 3, k = t - 3 * slot;
+        if (group_first + slot >= shard_count) continue;
+        const int i = shard_begin + group_first + slot;
+        Affine128 j_a, j_b;
+        if (direct)
+            j_a = a.task_jump[3 * i + k];
+        else
+        {
+            j_a = a.jump_hi[i >> 8];
+            j_b = a.jump_lo[i & 255];
+        }
+        compute_draw<T>(a, ctl.state2, j_a, j_b, direct, k, write_base + i);
+    }
+}
+
 template <class T, class Calc, int EPL, int LPW>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + 1))
 stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                          int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     // `a` is the launch description in the kernarg segment; the h_* locals are the preloaded copies of the
     // fields every wavefront needs before its first memory access (same values, no kernarg fetch)
     const HalfStepArgs<T>& a = rest;
-    DrawRec<T>* const h_draws = hot_draws;
+    const int h_color = (int)((hot_bits >> 20) & 1u);
+    const int h_parity = (int)((hot_bits >> 24) & 1u);
+    const bool h_draw_wave = ((hot_bits >> 25) & 1u) != 0;
+    // draw records: this launch reads buffer `parity`, the draws of the colour's next update go to the other one
+    const DrawRec<T>* const h_draws = hot_draws + ((size_t)h_parity * 2 + (size_t)h_color) * (size_t)hot_n;
+    DrawRec<T>* const h_draws_next = hot_draws + ((size_t)(1 - h_parity) * 2 + (size_t)h_color) * (size_t)hot_n;
     T* const h_pos = hot_pos;
     T* const h_logp = hot_logp;
     uint32_t* const h_n_accept = hot_n_accept;
     const int h_n = hot_n;
     const int h_dims = (int)(hot_bits & 0xFFFu);
     const int h_passes = (int)((hot_bits >> 12) & 0xFFu);
-    const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_vec_ok = (int)((hot_bits >> 21) & 1u);
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
     const int h_shard_begin = hot_shard_begin;
@@ -302,8 +357,17 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
 #endif
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int wave = blockIdx.x * kWavesPerBlock + wib;
     const int nw = WPP * h_passes;
+    if (wib == kWavesPerBlock)
+    {
+        // the workgroup's extra wavefront: next draws of every walker this workgroup updates
+        const StepCtl ctl_d = *hot_ctl_in;
+        if (Calc::block_scratch_elems(h_dims) != 0) __syncthreads();  // keep the workgroup barrier count whole
+        draw_wave_body<T>(a, ctl_d, h_draws_next, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * nw,
+                          kWavesPerBlock * nw, lane);
+        return;
+    }
+    const int wave = blockIdx.x * kWavesPerBlock + wib;
     const int first = wave * nw;  // first walker of this wavefront, relative to the shard
     const bool wave_active = first < h_shard_count;
     const int half_base = h_color ? h_n : 0;
@@ -332,7 +396,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         const int li0 = first + grp;
         const bool act0 = wave_active && li0 < h_shard_count;
         const int w0 = half_base + h_shard_begin + (act0 ? li0 : 0);
-        rec = h_draws[w0];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
+        rec = h_draws[w0 - half_base];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
         load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
         lp_old = h_logp[w0];
         nacc_old = h_n_accept[w0];  // every lane of the group reads the same word: no divergent branch, no wait
@@ -373,24 +437,9 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     typename Calc::template Regs<EPL, LPW> cregs;
     Calc::template preload<EPL, LPW>(ctx, a.calc_params, cregs);
 
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        // hand the stream and the counters to the next half-step
-        StepCtl nx = ctl;
-        nx.state = apply(a.half_jump, ctl.state);
-        nx.state2 = apply(a.half_jump, ctl.state2);
-        nx.half_step = ctl.half_step + 1;
-        if (h_color)
-        {
-            // the ensemble step ends with the black half: advance the per-step counters
-            const bool saved = ctl.save_phase + 1u == (uint32_t)run.interval;
-            nx.step_in_run = ctl.step_in_run + 1;
-            nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
-            nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
-            nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
-        }
-        *a.ctl_out = nx;
-    }
+    // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
+    // in the extra wavefront it would lengthen the last wavefront to finish: measured)
+    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over<T>(a, ctl, run, h_color);
     if (!wave_active) return;
 
     // does this ensemble step go to the chain?  (EnsembleSampler.h:298-306: interval-1 unsaved, 1 saved)
@@ -422,12 +471,13 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
                         j_b = a.jump_lo[i & 255];
                     }
                 }
-                compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k, h_draws + half_base + i);
+                compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k, h_draws_next + i);
             }
         }
     };
-    const bool draws_first = h_passes == 1;
-    if (draws_first) next_draws();
+    // (the record buffers alternate, so the order against the update loop no longer matters for correctness;
+    //  in the shadow of the gather is where the arithmetic costs least)
+    if (!h_draw_wave) next_draws();
     MCMCPP_STAMP(2);  // next draws done
 
     // ---------------- the update: LPW lanes per walker ------------------------------------------------------
@@ -449,7 +499,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
             const int lin = li + WPP;
             const bool actn = lin < h_shard_count;
             const int wn = half_base + h_shard_begin + (actn ? lin : 0);
-            rec_next = h_draws[wn];
+            rec_next = h_draws[wn - half_base];
             load_slice<T, EPL>(h_pos + (size_t)wn * h_dims, i0, h_dims, vec_ok, actn, own_next);
             lp_next = h_logp[wn];
             nacc_next = h_n_accept[wn];
@@ -507,7 +557,6 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         nacc_old = nacc_next;
         rec = rec_next;
     }
-    if (!draws_first) next_draws();
     MCMCPP_STAMP(5);  // all stores of this wavefront acknowledged
 #ifdef MCMCPP_STAMPS
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
@@ -541,7 +590,7 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
         j_a = a.jump_hi[i >> 8];
         j_b = a.jump_lo[i & 255];
     }
-    compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + (a.color ? a.n : 0) + i);
+    compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + ((size_t)a.draw_parity * 2 + (size_t)a.color) * (size_t)a.n + i);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -559,7 +608,7 @@ typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
 // P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
 template <class T, class Calc, int EPL, int LPW, int P>
-__global__ void __launch_bounds__(64 * kWavesPerBlock)
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + 1))
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
@@ -578,18 +627,30 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     stamp_val[6] = __builtin_amdgcn_s_memrealtime();
 #endif
     MCMCPP_STAMP(0);
-    DrawRec<T>* const h_draws = hot_draws;
+    const int h_color = (int)((hot_bits >> 20) & 1u);
+    const int h_parity = (int)((hot_bits >> 24) & 1u);
+    const bool h_draw_wave = ((hot_bits >> 25) & 1u) != 0;
+    const DrawRec<T>* const h_draws = hot_draws + ((size_t)h_parity * 2 + (size_t)h_color) * (size_t)hot_n;
+    DrawRec<T>* const h_draws_next = hot_draws + ((size_t)(1 - h_parity) * 2 + (size_t)h_color) * (size_t)hot_n;
     T* const h_pos = hot_pos;
     T* const h_logp = hot_logp;
     uint32_t* const h_n_accept = hot_n_accept;
     const int h_n = hot_n;
     const int h_dims = (int)(hot_bits & 0xFFFu);
-    const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
     const int h_shard_begin = hot_shard_begin;
     const int h_shard_count = hot_shard_count;
 
     const int lane = threadIdx.x & 63;
+    if ((threadIdx.x >> 6) == kWavesPerBlock)
+    {
+        // the workgroup's extra wavefront: next draws of every walker this workgroup updates
+        const StepCtl ctl_d = *hot_ctl_in;
+        __syncthreads();  // the matrix barrier of the updating wavefronts
+        draw_wave_body<T>(a, ctl_d, h_draws_next, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW,
+                          lane);
+        return;
+    }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int first = wave * NW;
     const bool wave_active = first < h_shard_count;
@@ -615,7 +676,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         const int li = first + 4 * q + grp;
         active[q] = wave_active && li < h_shard_count;
         w[q] = half_base + h_shard_begin + (active[q] ? li : 0);
-        rec[q] = h_draws[w[q]];
+        rec[q] = h_draws[w[q] - half_base];
         {
             const V2 v = *reinterpret_cast<const V2*>(h_pos + (size_t)w[q] * h_dims + i0c);
             own[q][0] = (active[q] && col_ok) ? v.x : (T)0;
@@ -625,7 +686,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         nacc_old[q] = h_n_accept[w[q]];  // every lane of the group reads the same word: no divergent branch, no wait
     }
     typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);
+    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);  // updating wavefronts only
 
     const StepCtl ctl = *hot_ctl_in;
     const RunInfo run = *a.run;
@@ -656,30 +717,17 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // ---- in its shadow: the matrix goes to LDS, hand-over to the next launch, the walkers' next draws ----------------
     Calc::block_commit(calc_pf, sh_pt, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);
     __syncthreads();
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-    {
-        StepCtl nx = ctl;
-        nx.state = apply(a.half_jump, ctl.state);
-        nx.state2 = apply(a.half_jump, ctl.state2);
-        nx.half_step = ctl.half_step + 1;
-        if (h_color)
-        {
-            const bool saved = ctl.save_phase + 1u == (uint32_t)run.interval;
-            nx.step_in_run = ctl.step_in_run + 1;
-            nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
-            nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
-            nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
-        }
-        *a.ctl_out = nx;
-    }
+    // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
+    // in the extra wavefront it would lengthen the last wavefront to finish: measured)
+    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over<T>(a, ctl, run, h_color);
     if (!wave_active) return;
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
         save_slot = a.direct_save_slot;
     else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
-    if (lane < 3 * NW && first + slot_a < h_shard_count)
-        compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws + half_base + h_shard_begin + first + slot_a);
+    if (!h_draw_wave && lane < 3 * NW && first + slot_a < h_shard_count)
+        compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
     MCMCPP_STAMP(2);  // next draws done
 
     // ---- proposals (StretchMove.h:105-108), staged as rows of X ---------------------------------------------------
