@@ -240,7 +240,13 @@ def main():
     if rank == 0:
         bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8          # 784 B at D = 32, fp64
         saved_fraction = 1.0 / args.interval
-        bytes_per_launch = (W // 2) * (bytes_per_update + saved_fraction * D * 8)
+        # walker updates one launch performs: W/2 for the half-step kernels, W when the library steps with one
+        # launch per ensemble step (full_step_kernel.hpp)
+        updates_per_launch = walker_steps / launches
+        full_step = updates_per_launch > 0.75 * W
+        kernel = ("stretch_full_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>" if full_step else
+                  "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16, P=2>")
+        bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * 8)
         us_per_launch = gpu_ms * 1e3 / launches
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
         # HBM bytes per launch from the PMC counters: collected by a separate rocprofv3 --pmc run of this very
@@ -248,7 +254,9 @@ def main():
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if args.calc == "dense" and (W, D) == (16384, 32) and os.path.exists(pmc_path):
-            traffic = json.load(open(pmc_path))["hbm_bytes_per_launch"]
+            pmc = json.load(open(pmc_path))
+            if pmc.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+                traffic = pmc["hbm_bytes_per_launch"]
         line = {
             "metric": "walker-steps/sec + acceptance rate, 16384 walkers x 32 dims, 1/2/4/8 GPU",
             "value": walker_steps / elapsed,
@@ -272,13 +280,14 @@ def main():
                        "slicing_interval": args.interval, "chains": world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16, P=2>",
+                         "kernel": kernel,
+                         "walker_updates_per_launch": updates_per_launch,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "avg_launch_us": us_per_launch,
                          "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                            "passes; FETCH_SIZE doubled per the gfx950 correction)" if traffic else None,
                          "note": "avg launch duration = HIP-event time on the launch stream over the graph-replayed "
-                                 "half-step launches / launches; it includes the ~1.5 us dependent-launch boundary"},
+                                 "step launches / launches; it includes the ~1.5 us dependent-launch boundary"},
         }
         if args.calc != "dense":
             line["config"]["workload"] += " [EXPERIMENT: calculator = %s, not the headline workload]" % args.calc

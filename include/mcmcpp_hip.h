@@ -154,8 +154,9 @@ int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t c
 /* ---- measurement ---------------------------------------------------------------------------------- */
 
 /* GPU time of the last mcmcpp_hip_run between HIP events recorded on the launch stream around the
- * half-step launches (excludes uploads / downloads), and the number of half-step launches it covers. */
-int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* half_step_launches);
+ * step launches (excludes uploads / downloads), and the number of step-kernel launches it covers: one per
+ * ensemble step for ensembles small enough to be stepped by the full-step kernel, two (red, black) otherwise. */
+int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* step_launches);
 
 /* ---- multi-GPU single ensemble (one handle per GPU) -------------------------------- */
 

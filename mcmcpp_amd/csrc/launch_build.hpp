@@ -21,10 +21,28 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * 33) * sizeof(T);
+    const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave);
     hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? 1 : 0))), lds, st,
                        a.draws, a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+}
+
+template <class T, class Calc, int EPL, int LPW>
+void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave), a.pos_parity);
+    hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
+                       st, a.draws, a.pos, a.pos_alt, a.logp, a.logp_alt, a.n_accept, a.n, bits, a.ctl_in, a);
+}
+
+template <class T, class Calc, int EPL, int LPW>
+void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1), a.pos_parity);
+    hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+                       a.pos, a.pos_alt, a.logp, a.logp_alt, a.n_accept, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>
@@ -40,10 +58,12 @@ void put(LaunchTable<T>& t)
 {
     constexpr int kBase = Vec16<T>::N;
     t.half_step[LPWLOG][EPLSHIFT] = &launch_half<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+    t.full_step[LPWLOG][EPLSHIFT] = &launch_full<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     if constexpr (Calc::template MatrixCore<(kBase << EPLSHIFT), (1 << LPWLOG)>::kUse)
     {
         t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
         t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
+        t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
 }

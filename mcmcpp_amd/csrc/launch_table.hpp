@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "full_step_kernel.hpp"
 #include "stretch_kernel.hpp"
 
 namespace mcmcpp
@@ -12,7 +13,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430005u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430008u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -27,10 +28,15 @@ struct LaunchTable
     CalcFn calc[kLpwLevels][kMaxEplShift];
     // matrix-core variants (nullptr where the calculator has none): need even D and exactly 2 ([0]) / 4 ([1]) passes
     HalfStepFn half_step_mc[2][kLpwLevels][kMaxEplShift];
+    // one launch per ensemble step (full_step_kernel.hpp); grid counts workgroups of 4 x (64/LPW) walkers per colour
+    // (generic) or 32 per colour (matrix-core variant)
+    HalfStepFn full_step[kLpwLevels][kMaxEplShift];
+    HalfStepFn full_step_mc[kLpwLevels][kMaxEplShift];
 };
 
-void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, hipStream_t stream);
-void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, hipStream_t stream);
+// red_base != nullptr: black records, with partner2 (see DrawRec)
+void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, const U128* red_base, hipStream_t stream);
+void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_base, hipStream_t stream);
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream);
 

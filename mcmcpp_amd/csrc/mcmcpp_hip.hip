@@ -4,8 +4,9 @@
 // Reference roles replaced (paths relative to /root/reference):
 //   EnsembleSampler ctor / setInitialWalkerPos / runMCMC / reset / counters  MCMCpp/EnsembleSampler.h:199-360
 //   ParallelEnsembleSampler's thread pool + red/black controller             MCMCpp/Threading/*.h
-//     -> one kernel launch per half-step on one HIP stream, replayed from a hipGraph; the stream and
-//        step counters travel in device memory (StepCtl) so a replay needs no host-side updates
+//     -> one kernel launch per ensemble step (small ensembles: full_step_kernel.hpp) or per half-step (large ones)
+//        on one HIP stream, replayed from a hipGraph; the stream and step counters travel in device memory
+//        (StepCtl) so a replay needs no host-side updates
 //   Walker[] (heap row per walker)  MCMCpp/Walker/Walker.h:142-149 -> pos[W][D], logp[W], n_accept[W] in HBM
 #include <hip/hip_runtime.h>
 
@@ -114,15 +115,15 @@ const LaunchTable<float>* table_for<float>(int calc_id)
 
 namespace mcmcpp
 {
-void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, hipStream_t stream)
+void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, const U128* red_base, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
-    hipLaunchKernelGGL(fill_draws_kernel<double>, dim3(grid), dim3(256), 0, stream, a, base);
+    hipLaunchKernelGGL(fill_draws_kernel<double>, dim3(grid), dim3(256), 0, stream, a, base, red_base ? *red_base : base, red_base ? 1 : 0);
 }
-void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, hipStream_t stream)
+void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_base, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
-    hipLaunchKernelGGL(fill_draws_kernel<float>, dim3(grid), dim3(256), 0, stream, a, base);
+    hipLaunchKernelGGL(fill_draws_kernel<float>, dim3(grid), dim3(256), 0, stream, a, base, red_base ? *red_base : base, red_base ? 1 : 0);
 }
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream)
@@ -246,6 +247,22 @@ public:
             passes = big ? 4 : 2;
         }
 
+        // One launch per ensemble step (full_step_kernel.hpp) while the ensemble is small enough that a half-step
+        // launch is bounded by its launch boundary and latencies rather than by HBM; needs the whole ensemble here.
+        full_fn = nullptr;
+        if (shard_count == n && shard_begin == 0 && env_long("MCMCPP_HIP_FULL_STEP", 1) != 0 &&
+            W <= env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 24576))
+        {
+            full_fn = table->full_step[lpw_log][epl_shift];
+            full_wpb = kWavesPerBlock * (64 / lpw);
+            if (table->full_step_mc[lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min &&
+                c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN)  // (it reads the padded matrix this file prepares)
+            {
+                full_fn = table->full_step_mc[lpw_log][epl_shift];
+                full_wpb = kWavesPerBlock * 8;
+            }
+        }
+
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
         {
             stream = (hipStream_t)c.hip_stream;  // may be the null (legacy default) stream
@@ -276,7 +293,8 @@ public:
             HIP_TRY(hipMalloc(&d_pos, sizeof(T) * (size_t)W * D));
             own_pos = true;
         }
-        HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
+        HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W * 2));  // [2][W]: the second half is the full-step kernels' other buffer
+        if (full_fn) HIP_TRY(hipMalloc(&d_pos_alt, sizeof(T) * (size_t)W * D));
         HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMalloc(&d_ctl, sizeof(StepCtl) * 2));
         HIP_TRY(hipMalloc(&d_run, sizeof(RunInfo)));
@@ -284,8 +302,8 @@ public:
         HIP_TRY(hipMalloc(&d_draws, sizeof(DrawRec<T>) * (size_t)W * 2));  // two buffers: see HalfStepArgs::draws
         HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2));
 #ifdef MCMCPP_STAMPS
-        HIP_TRY(hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d_stamps, 0, 8 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&d_stamps, kStampWords * sizeof(unsigned long long)));  // [8 stamps][2 alternating launches][start, end of 4096 workgroups | end of their draw wavefronts]
+        HIP_TRY(hipMemset(d_stamps, 0, kStampWords * sizeof(unsigned long long)));
 #endif
         HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
@@ -305,6 +323,15 @@ public:
             }
             HIP_TRY(hipMalloc(&d_params, sizeof(T) * prm.size()));
             HIP_TRY(hipMemcpy(d_params, prm.data(), sizeof(T) * prm.size(), hipMemcpyHostToDevice));
+            if (c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN && D <= 32)
+            {
+                // the matrix-core kernels read P^T zero-padded to 32 x 32 straight into registers
+                std::vector<T> pad((size_t)32 * 32, (T)0);
+                for (int k = 0; k < D; ++k)
+                    for (int i = 0; i < D; ++i) pad[(size_t)k * 32 + i] = prm[(size_t)k * D + i];
+                HIP_TRY(hipMalloc(&d_params_padded, sizeof(T) * pad.size()));
+                HIP_TRY(hipMemcpy(d_params_padded, pad.data(), sizeof(T) * pad.size(), hipMemcpyHostToDevice));
+            }
         }
 
         // pcg64 stream (MultiSampler.h:54) and its jump tables
@@ -336,7 +363,8 @@ public:
 
         graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 64) : c.graph_steps;
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
-        partial_waves = (int)grid_blocks() * kWavesPerBlock;
+        partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
+        if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;
         HIP_TRY(hipMalloc(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
         HIP_TRY(hipMemset(d_partials, 0, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
         chain_subchunk_bytes = (size_t)env_long("MCMCPP_HIP_CHAIN_SUBCHUNK_MB", 32) << 20;
@@ -395,6 +423,7 @@ public:
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
         enq_step = half_steps >> 1;
+        run_step = 0;
         args_red = make_args(0);
         args_blk = make_args(1);
         rc = ensure_graphs();
@@ -431,8 +460,19 @@ public:
             if (chain_out)
             {
                 // the staging buffer is free: its previous content (sub-chunk c-2) was copied out below
-                HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], step_bytes * (size_t)now, hipMemcpyDeviceToHost, stream));
-                HIP_TRY(hipEventRecord(ev_copied[buf], stream));
+                if (copy_stream)
+                {
+                    // the download runs beside the next sub-chunk's launches (which fill the other device half)
+                    HIP_TRY(hipEventRecord(ev_filled[buf], stream));
+                    HIP_TRY(hipStreamWaitEvent(copy_stream, ev_filled[buf], 0));
+                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], step_bytes * (size_t)now, hipMemcpyDeviceToHost, copy_stream));
+                    HIP_TRY(hipEventRecord(ev_copied[buf], copy_stream));
+                }
+                else
+                {
+                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], step_bytes * (size_t)now, hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipEventRecord(ev_copied[buf], stream));
+                }
                 if (pending_first >= 0)
                 {
                     HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
@@ -451,6 +491,14 @@ public:
                 HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
                 std::memcpy((char*)chain_out + step_bytes * (size_t)pending_first, h_stage[pending_buf], step_bytes * (size_t)pending_count);
             }
+            if (full_fn && (run_step & 1))
+            {
+                // an odd number of full steps leaves the ensemble in the second buffer: bring it (and the control
+                // record) home, so that everything outside run() only ever knows the first
+                HIP_TRY(hipMemcpyAsync(d_pos, d_pos_alt, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_logp, d_logp + W, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_ctl, d_ctl + 1, sizeof(StepCtl), hipMemcpyDeviceToDevice, stream));
+            }
             HIP_TRY(hipStreamSynchronize(stream));
             for (int64_t c = (n_sub > 3 ? n_sub - 3 : 0); c < n_sub; ++c)
             {
@@ -459,7 +507,7 @@ public:
                 launch_ms += ms;
             }
             last_ms = launch_ms;
-            last_launches = 2 * total;
+            last_launches = full_fn ? total : 2 * total;
             half_steps += 2 * (uint64_t)total;
             steps_since_reset += (uint64_t)total;
             if (accepted_per_step)
@@ -603,7 +651,7 @@ public:
     {
         if (!d_stamps) return fail(MCMCPP_HIP_E_UNSUPPORTED, "not a diagnostic build");
         HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipMemcpy(out8, d_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out8, d_stamps, kStampWords * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         return MCMCPP_HIP_OK;
     }
 
@@ -640,6 +688,8 @@ private:
         const long waves = (shard_count + per_wave - 1) / per_wave;
         return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     }
+
+    unsigned full_grid_blocks() const { return (unsigned)((n + full_wpb - 1) / full_wpb); }
 
     HalfStepArgs<T> make_args(int color, int parity) const
     {
@@ -691,6 +741,10 @@ private:
         a.use_ctl_save = 1;
         a.stamps = d_stamps;
         a.draw_parity = 0;
+        a.pos_alt = d_pos_alt;
+        a.logp_alt = d_logp + W;
+        a.pos_parity = 0;
+        a.calc_params_padded = d_params_padded;
         // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
         a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
         return a;
@@ -712,15 +766,29 @@ private:
         HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
         // the draw records of the next red and the next black half-step (afterwards the launches keep them going)
         const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
-        launch_fill_draws(make_args(0, parity), c->state, stream);
-        launch_fill_draws(make_args(1, parity), state1, stream);
+        launch_fill_draws(make_args(0, parity), c->state, nullptr, stream);
+        launch_fill_draws(make_args(1, parity), state1, full_fn ? &c->state : nullptr, stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MCMCPP_HIP_OK;
     }
 
-    void enqueue_step(int parity)
+    // pos_parity: which position buffer a full-step launch reads (ensemble steps enqueued in this run() & 1)
+    void enqueue_step(int parity, int pos_parity)
     {
+        if (full_fn)
+        {
+            HalfStepArgs<T>& a = args_red;
+            a.draw_parity = parity;
+            a.pos_parity = pos_parity;
+            a.ctl_in = d_ctl + pos_parity;
+            a.ctl_out = d_ctl + (1 - pos_parity);
+            a.partial_waves = partial_waves;
+            // the next draws by four extra wavefronts (two per colour) when that is one round of 64 draws each
+            a.draw_wave = (3 * ((full_wpb + 1) / 2) <= 64 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
+            full_fn(a, full_grid_blocks(), stream);
+            return;
+        }
         args_red.draw_parity = parity;
         args_blk.draw_parity = parity;
         half_fn(args_red, grid_blocks(), stream);
@@ -730,16 +798,16 @@ private:
     // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
     // graph_steps for the bulk, one graph per distinct remainder)
     // (the record-buffer parity of every node is frozen into the graph, hence one graph per starting parity)
-    int graph_for(int steps, int start_parity, hipGraphExec_t* out)
+    int graph_for(int steps, int start_parity, int pos_parity, hipGraphExec_t* out)
     {
-        const size_t key = (size_t)steps * 2 + (size_t)start_parity;
+        const size_t key = (size_t)steps * 4 + (size_t)start_parity * 2 + (size_t)pos_parity;
         if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
         if (!graph_cache[key])
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            for (int s = 0; s < steps; ++s) enqueue_step((start_parity + s) & 1);
-            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, d_ctl, d_run, stream);
+            for (int s = 0; s < steps; ++s) enqueue_step((start_parity + s) & 1, (pos_parity + s) & 1);
+            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -754,8 +822,12 @@ private:
     {
         if (graph_steps < 1) return MCMCPP_HIP_OK;
         hipGraphExec_t ex;
-        return graph_for(graph_steps, (int)(enq_step & 1), &ex);
+        return graph_for(graph_steps, (int)(enq_step & 1), 0, &ex);
     }
+
+    // the control record the last launch of a step sequence leaves behind: the half-step pair always ends in [0],
+    // full-step launches alternate with the position buffers
+    const StepCtl* ctl_after(int64_t pos_parity_after) const { return d_ctl + (full_fn ? (pos_parity_after & 1) : 0); }
 
     // enqueue `steps` ensemble steps on the launch stream (graph replays, or plain launches when graphs are off)
     int enqueue_steps(int64_t steps)
@@ -767,27 +839,30 @@ private:
             hipGraphExec_t ex = nullptr;
             while (left >= graph_steps)
             {
-                int rc = graph_for(graph_steps, (int)(enq_step & 1), &ex);
+                int rc = graph_for(graph_steps, (int)(enq_step & 1), (int)(run_step & 1), &ex);
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
                 left -= graph_steps;
                 enq_step += (uint64_t)graph_steps;
+                run_step += (uint64_t)graph_steps;
             }
             if (left > 0)
             {
-                int rc = graph_for((int)left, (int)(enq_step & 1), &ex);  // one replay for the remainder
+                int rc = graph_for((int)left, (int)(enq_step & 1), (int)(run_step & 1), &ex);  // one replay for the remainder
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
                 enq_step += (uint64_t)left;
+                run_step += (uint64_t)left;
             }
         }
         else
         {
             for (; left > 0; --left)
             {
-                enqueue_step((int)(enq_step & 1));
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, d_ctl, d_run, stream);
+                enqueue_step((int)(enq_step & 1), (int)(run_step & 1));
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
                 enq_step += 1;
+                run_step += 1;
             }
             HIP_TRY(hipGetLastError());
         }
@@ -808,7 +883,11 @@ private:
             acc_capacity = acc_entries;
         }
         if (half_bytes > 0 && ev_copied[0] == nullptr)
+        {
             for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ev_copied[k], hipEventDisableTiming));
+            for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ev_filled[k], hipEventDisableTiming));
+            if (env_long("MCMCPP_HIP_COPY_STREAM", 0) != 0) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        }
         if (half_bytes > chain_half_capacity)
         {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -841,6 +920,7 @@ private:
         for (hipGraphExec_t ex : graph_cache)
             if (ex) hipGraphExecDestroy(ex);
         if (own_pos && d_pos) hipFree(d_pos);
+        if (d_pos_alt) hipFree(d_pos_alt);
         if (d_logp) hipFree(d_logp);
         if (d_nacc) hipFree(d_nacc);
         if (d_ctl) hipFree(d_ctl);
@@ -854,8 +934,10 @@ private:
             if (d_chain[k]) hipFree(d_chain[k]);
             if (h_stage[k]) hipHostFree(h_stage[k]);
             if (ev_copied[k]) hipEventDestroy(ev_copied[k]);
+            if (ev_filled[k]) hipEventDestroy(ev_filled[k]);
         }
         if (d_params) hipFree(d_params);
+        if (d_params_padded) hipFree(d_params_padded);
         if (d_jump_lo) hipFree(d_jump_lo);
         if (d_jump_hi) hipFree(d_jump_hi);
         if (d_task_jump) hipFree(d_task_jump);
@@ -865,29 +947,40 @@ private:
             if (ev_t0[k]) hipEventDestroy(ev_t0[k]);
             if (ev_t1[k]) hipEventDestroy(ev_t1[k]);
         }
+        if (copy_stream)
+        {
+            hipStreamSynchronize(copy_stream);
+            hipStreamDestroy(copy_stream);
+        }
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
     mcmcpp_hip_config cfg;
     const LaunchTable<T>* table = nullptr;
     typename LaunchTable<T>::HalfStepFn half_fn = nullptr;
+    typename LaunchTable<T>::HalfStepFn full_fn = nullptr;  // non-null: run() steps with one launch per ensemble step
+    int full_wpb = 1;                                       // walkers of each colour per full-step workgroup
+    T* d_pos_alt = nullptr;
+    uint64_t run_step = 0;                                  // ensemble steps enqueued in the current run()
     typename LaunchTable<T>::CalcFn calc_fn = nullptr;
     int W = 0, D = 0, n = 0, lpw = 1, epl = 1, passes = 1, vec_ok = 0, num_cus = 256;
     int shard_begin = 0, shard_count = 0, device = -1, graph_steps = 32;
     size_t chain_subchunk_bytes = 0, chain_half_capacity = 0, acc_capacity = 0;
-    hipEvent_t ev_copied[2] = {nullptr, nullptr};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_filled[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;  // experiment (MCMCPP_HIP_COPY_STREAM=1): chain downloads beside the launches
     T* d_chain[2] = {nullptr, nullptr};
     void* h_stage[2] = {nullptr, nullptr};
     uint32_t* d_acc = nullptr;
     hipStream_t stream = nullptr;
     bool own_stream = false, own_pos = false, have_state = false, stream_valid = false;
     hipEvent_t ev_t0[4] = {nullptr, nullptr, nullptr, nullptr}, ev_t1[4] = {nullptr, nullptr, nullptr, nullptr};
-    T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr;
+    T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_params_padded = nullptr;
     uint32_t* d_nacc = nullptr;
     StepCtl* d_ctl = nullptr;
     RunInfo* d_run = nullptr;
     Diag* d_diag = nullptr;
     DrawRec<T>* d_draws = nullptr;
+    static constexpr size_t kStampWords = 8 + 2 * 3 * 4096 + 8;
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     uint32_t* d_partials = nullptr;
     int partial_slots = 1, partial_waves = 0;
@@ -1068,10 +1161,10 @@ int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t c
     NEED_H;
     return h->calc_logp(positions, count, logp_out);
 }
-int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* half_step_launches)
+int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* step_launches)
 {
     NEED_H;
-    return h->last_run_timing(gpu_ms, half_step_launches);
+    return h->last_run_timing(gpu_ms, step_launches);
 }
 int mcmcpp_hip_half_step_async(mcmcpp_hip_sampler* h, int32_t color, int64_t save_slot)
 {

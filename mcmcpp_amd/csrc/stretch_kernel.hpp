@@ -14,9 +14,11 @@
 //            gather the partner row, form the proposal, evaluate the Calculator functor (cross-lane tree
 //            reduction), Metropolis accept in place, optional chain store, per-step accepted count
 //   draws    (one lane per draw): the random draws do not depend on the walkers, so the three draws each of
-//            these walkers needs at its NEXT update (two half-steps ahead: same colour, same wavefront) are
-//            computed now, in the shadow of the partner-row gather, and left in a 32-byte record per walker.
-//            The launch's dependent chain is then two memory round trips plus the calculator.
+//            these walkers needs at its NEXT update (two half-steps ahead) are computed now and left in a
+//            32-byte record per walker, in the other of two record buffers.  A fifth wavefront per workgroup
+//            does nothing else (for wide lane groups; otherwise the updating wavefronts do it in the shadow of
+//            their partner-row gather).  The launch's dependent chain is then two memory round trips plus the
+//            calculator.
 // No MFMA here: the work is element-wise plus a per-walker reduction (calculators with a dense product have a
 // matrix-core variant further down).
 #pragma once
@@ -62,7 +64,8 @@ struct alignas(16) DrawRec
     T zs;              // (D-1) ln z
     T ln_u;            // ln U of the accept test
     uint32_t partner;  // index inside the complementary half
-    uint32_t pad_;
+    uint32_t partner2; // black records made for the full-step kernels only: the partner (a black walker) of this walker's
+                       // red partner in the same ensemble step, so that both rows can be fetched in one round trip
 };
 
 struct Diag
@@ -71,45 +74,58 @@ struct Diag
     unsigned long long redraws;
 };
 
+// The launch description.  It travels by value in the kernarg segment (behind 64 bytes of preloaded hot arguments)
+// and is read with scalar loads where a field is first used; after a launch boundary every 64-byte line of it is a
+// cold miss of several hundred ns, so the fields are grouped by who needs them first: a draw wavefront touches the
+// first two lines only (the next two as well with the two-level jump tables).
 template <class T>
-struct HalfStepArgs
+struct alignas(64) HalfStepArgs
 {
-    T* pos;                  // [W][D]
-    T* logp;                 // [W]
-    uint32_t* n_accept;      // [W]
+    // ---- line 0: the random stream (draw wavefronts, fill_draws_kernel) ----
+    const Affine128* task_jump; // [3n] map of t+1 draws (base state -> state behind draw t), or nullptr for large n
+    const Affine128* jump_hi;   // [ceil(n/256)] map of 3*256*m draws
+    const Affine128* jump_lo;   // [256]   map of 3*k draws
+    Diag* diag;
+    Affine128 half_jump;        // map of 3*n draws: this half-step's base state -> the next one's
+    // ---- line 1: constants of the draws and of the accept test ----
+    uint64_t redraw_threshold;  // (2^64 - n) mod n (pcg bounded_rand)
+    T gw_term1, gw_inv_sqrt;    // GwDistribution<T,2,1> constants (MCMCpp/Utility/GwDistribution.h:45-55)
+    T dims_minus_one;           // (T)(D-1)  (StretchMove.h:110)
+    T tie_eps;
+    int n;                      // walkers per half
+    int n_is_pow2;
+    int dims;                   // D
+    int color;                  // 0 red = walkers [0,n), 1 black = [n,2n)
+    int shard_begin;            // first walker (index inside the half) updated by this launch
+    int shard_count;            // number of walkers updated by this launch
+    // ---- lines 2-3: two-level jump tables only; diagnostics ----
+    alignas(64) Affine128 draw_jump[3];  // maps of 1, 2, 3 draws: a walker's base state -> the state behind draw k
+    U128 inc;                   // pcg stream increment
+    unsigned long long* stamps; // diagnostic build only (MCMCPP_STAMPS): shader-clock stamps
+    // ---- the updating wavefronts ----
+    alignas(64) T* pos;         // [W][D]
+    T* logp;                    // [W]
+    uint32_t* n_accept;         // [W]
     const StepCtl* ctl_in;
     StepCtl* ctl_out;
     const RunInfo* run;
-    Diag* diag;
-    const Affine128* jump_lo; // [256]   map of 3*k draws
-    const Affine128* jump_hi; // [ceil(n/256)] map of 3*256*m draws
-    const Affine128* task_jump; // [3n] map of t+1 draws (base state -> state behind draw t), or nullptr for large n
     const T* calc_params;
-    DrawRec<T>* draws;        // [2 buffers][2 colours][n] records of the coming updates: the update of ensemble step s
-                              // reads buffer s&1 and the draws for step s+1 are written to the other one
-    Affine128 half_jump;      // map of 3*n draws: this half-step's base state -> the next one's
-    Affine128 draw_jump[3];   // maps of 1, 2, 3 draws: a walker's base state -> the state behind draw k
-    U128 inc;                 // pcg stream increment
-    uint64_t redraw_threshold; // (2^64 - n) mod n (pcg bounded_rand)
-    T gw_term1, gw_inv_sqrt;  // GwDistribution<T,2,1> constants (MCMCpp/Utility/GwDistribution.h:45-55)
-    T dims_minus_one;         // (T)(D-1)  (StretchMove.h:110)
-    T tie_eps;
-    int n;                    // walkers per half
-    int dims;                 // D
-    int color;                // 0 red = walkers [0,n), 1 black = [n,2n)
-    int shard_begin;          // first walker (index inside the half) updated by this launch
-    int shard_count;          // number of walkers updated by this launch
-    int passes;               // rounds of 64/LPW walkers per wavefront
-    int vec_ok;               // rows are 16-byte aligned multiples: use 128-bit accesses
-    int n_is_pow2;
+    DrawRec<T>* draws;          // [2 buffers][2 colours][n] records of the coming updates: the update of ensemble step s
+                                // reads buffer s&1 and the draws for step s+1 are written to the other one
     uint32_t* partials;         // [partial_slots][2][partial_waves] per-wavefront accepted counts, or nullptr
+    // full-step kernels only (full_step_kernel.hpp): the second position / log-posterior buffer
+    T* pos_alt;                 // [W][D]
+    T* logp_alt;                // [W]
+    const T* calc_params_padded; // matrix-core kernels: P^T zero-padded to 32 x 32 (row stride 32)
+    long long direct_save_slot; // >= 0: store into run->chain at this slot regardless of interval (sharded driver)
+    int passes;                 // rounds of 64/LPW walkers per wavefront
+    int vec_ok;                 // rows are 16-byte aligned multiples: use 128-bit accesses
     int partial_slots;          // ensemble steps between two runs of accepted_reduce_kernel
     int partial_waves;          // wavefronts of one half-step launch
-    unsigned long long* stamps; // diagnostic build only (MCMCPP_STAMPS): 8 shader-clock stamps of wavefront 0
-    long long direct_save_slot; // >= 0: store into run->chain at this slot regardless of interval (sharded driver)
     int use_ctl_save;           // 1: saving follows RunInfo.interval / StepCtl.step_in_run
     int draw_parity;            // ensemble step & 1: which record buffer this launch reads
-    int draw_wave;              // 1: the workgroup carries one extra wavefront that computes the next draws
+    int draw_wave;              // 1: the workgroup carries extra wavefronts that compute the next draws
+    int pos_parity;             // full-step kernels: 0: read pos/logp, write pos_alt/logp_alt; 1: the reverse
 };
 
 template <class T, int EPL>
@@ -142,11 +158,14 @@ __device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec
     }
 }
 
-template <class T, int EPL>
+// STREAM: non-temporal stores, for rows that every launch rewrites wholesale (the full-step kernels' `out` buffer):
+// they drain to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back,
+// which would lengthen the gap to the next launch (measured: 0.6 us per launch at 16384 x 32).
+template <class T, int EPL, bool STREAM = false>
 __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, const T (&val)[EPL])
 {
     constexpr int VN = Vec16<T>::N;
-    typedef typename Vec16<T>::type V;
+    typedef T VX __attribute__((ext_vector_type(VN)));
     if (vec_ok)
     {
 #pragma unroll
@@ -154,11 +173,13 @@ __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, 
         {
             if (i0 + v * VN < D)
             {
-                V x;
-                T* xs = reinterpret_cast<T*>(&x);
+                VX x;
 #pragma unroll
-                for (int k = 0; k < VN; ++k) xs[k] = val[v * VN + k];
-                *reinterpret_cast<V*>(row + i0 + v * VN) = x;
+                for (int k = 0; k < VN; ++k) x[k] = val[v * VN + k];
+                if (STREAM)
+                    __builtin_nontemporal_store(x, reinterpret_cast<VX*>(row + i0 + v * VN));
+                else
+                    *reinterpret_cast<VX*>(row + i0 + v * VN) = x;
             }
         }
     }
@@ -166,7 +187,13 @@ __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, 
     {
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
-            if (i0 + e < D) row[i0 + e] = val[e];
+            if (i0 + e < D)
+            {
+                if (STREAM)
+                    __builtin_nontemporal_store(val[e], row + i0 + e);
+                else
+                    row[i0 + e] = val[e];
+            }
     }
 }
 
@@ -195,10 +222,21 @@ constexpr int kWavesPerBlock = 4;
             if (threadIdx.x == 0) stamp_val[k] = t_;                                        \
         }                                                                                   \
     } while (0)
+// start / end of every workgroup's first wavefront on the chip-wide 100 MHz clock
+#define MCMCPP_STAMP_BLOCK(which)                                                                               \
+    do                                                                                                          \
+    {                                                                                                           \
+        if (a.stamps != nullptr && threadIdx.x == 0 && blockIdx.x < 4096)                                       \
+            a.stamps[8 + (a.pos_parity | a.color) * 3 * 4096 + 2 * blockIdx.x + (which)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define MCMCPP_STAMP(k) \
     do                  \
     {                   \
+    } while (0)
+#define MCMCPP_STAMP_BLOCK(which) \
+    do                            \
+    {                             \
     } while (0)
 #endif
 
@@ -214,13 +252,32 @@ struct LdsLayout
     __host__ static size_t bytes(int dims) { return block_offset() + Calc::block_scratch_elems(dims) * sizeof(T); }
 };
 
+// The launch description sits in the kernarg segment and is read with scalar loads wherever a field is first used;
+// after a launch boundary every one of its 64-byte lines is a cold miss (several hundred ns), and the compiler
+// places those loads lazily, one dependent miss after the other along a wavefront's path.  This touches all lines
+// at once and waits for them, so that every later field access hits the scalar cache: call it where a wait is
+// free (behind the first vector loads of an updating wavefront; first thing in a draw wavefront).
+// (The kernels' argument lists are 64 bytes of preloaded hot arguments followed by the HalfStepArgs: the struct
+// occupies bytes 64 .. 64 + sizeof of the kernarg segment; the hidden arguments follow it.)
+template <class T>
+__device__ __forceinline__ void warm_launch_args()
+{
+    static_assert(64 + sizeof(HalfStepArgs<T>) > 0x180 && 64 + sizeof(HalfStepArgs<T>) <= 0x200, "adjust the lines touched below");
+    typedef const __attribute__((address_space(4))) uint32_t* KernargPtr;
+    const KernargPtr k = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    const uint32_t t1 = k[0x40 / 4], t2 = k[0x80 / 4], t3 = k[0xc0 / 4], t4 = k[0x100 / 4], t5 = k[0x140 / 4], t6 = k[0x180 / 4], t7 = k[0x1c0 / 4];
+    asm volatile("" ::"s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));  // loaded and waited for, here
+}
+
 // One random draw of one walker: task k of the walker at position i of the half (draw 3*i + k of the
 // half-step whose base engine state is `base`), written into the walker's record.  k = 0: partner =
 // engine(n) (StretchMove.h:102); k = 1: z = Gw(u) and (D-1) ln z (StretchMove.h:104,110); k = 2:
 // ln U = -(-log(1-u)/1) (StretchMove.h:113).  One lane per draw keeps the dependent chain short.
+// In pieces, so that a caller with several draws per lane can overlap their memory accesses:
+
+// the raw 64-bit output of the task
 template <class T>
-__device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base, const Affine128& jump_a,
-                                             const Affine128& jump_b, bool direct, int k, DrawRec<T>* rec)
+__device__ __forceinline__ uint64_t draw_raw(const HalfStepArgs<T>& a, U128 base, const Affine128& jump_a, const Affine128& jump_b, bool direct, int k)
 {
     U128 s;
     if (direct)
@@ -231,11 +288,21 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
         const Affine128 dj = k == 0 ? a.draw_jump[0] : (k == 1 ? a.draw_jump[1] : a.draw_jump[2]);
         s = apply(dj, s);
     }
-    const uint64_t r = pcg_output(s);
+    return pcg_output(s);
+}
+template <class T>
+__device__ __forceinline__ uint32_t draw_partner(const HalfStepArgs<T>& a, uint64_t r)
+{
+    return a.n_is_pow2 ? (uint32_t)(r & (uint64_t)(a.n - 1)) : (uint32_t)(r % (uint64_t)a.n);
+}
+// the record fields of task k from its raw output
+template <class T>
+__device__ __forceinline__ void draw_store(const HalfStepArgs<T>& a, int k, uint64_t r, DrawRec<T>* rec)
+{
     if (k == 0)
     {
         if (r < a.redraw_threshold) atomicAdd(&a.diag->redraws, 1ULL);
-        rec->partner = a.n_is_pow2 ? (uint32_t)(r & (uint64_t)(a.n - 1)) : (uint32_t)(r % (uint64_t)a.n);
+        rec->partner = draw_partner<T>(a, r);
     }
     else
     {
@@ -251,6 +318,34 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
         }
         else
             rec->ln_u = lg;
+    }
+}
+// Black records made for the full-step kernels: the partner draw of this walker's red partner j (draw 3*j + 0
+// of the red half-step of the same ensemble step, base state `red_base`), kept as partner2.
+template <class T>
+__device__ __forceinline__ void draw_partner2_jump(const HalfStepArgs<T>& a, uint32_t j, bool direct, Affine128& g_a, Affine128& g_b)
+{
+    g_a = *(direct ? a.task_jump + 3 * (size_t)j : a.jump_hi + (j >> 8));  // branch-free: one pointer, one load
+    g_b = a.jump_lo[direct ? 0u : (j & 255u)];
+}
+template <class T>
+__device__ __forceinline__ uint32_t draw_partner2(const HalfStepArgs<T>& a, U128 red_base, const Affine128& g_a, const Affine128& g_b, bool direct)
+{
+    return draw_partner<T>(a, draw_raw<T>(a, red_base, g_a, g_b, direct, 0));
+}
+
+template <class T>
+__device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base, const Affine128& jump_a,
+                                             const Affine128& jump_b, bool direct, int k, DrawRec<T>* rec, bool with_partner2 = false,
+                                             U128 red_base = U128())
+{
+    const uint64_t r = draw_raw<T>(a, base, jump_a, jump_b, direct, k);
+    draw_store<T>(a, k, r, rec);
+    if (with_partner2 && k == 0)
+    {
+        Affine128 g_a, g_b;
+        draw_partner2_jump<T>(a, draw_partner<T>(a, r), direct, g_a, g_b);
+        rec->partner2 = draw_partner2<T>(a, red_base, g_a, g_b, direct);
     }
 }
 
@@ -289,29 +384,96 @@ __device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCt
 }
 
 // Body of the workgroup's extra wavefront (when HalfStepArgs::draw_wave): the next draws of all walkers the
-// workgroup updates, `group_walkers` of them starting at `group_first` (relative to the shard).  It runs beside
-// the updating wavefronts, so the draw arithmetic is on nobody's critical path.
-template <class T>
-__device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const StepCtl& ctl, DrawRec<T>* write_base, int shard_begin,
-                                               int shard_count, int group_first, int group_walkers, int lane)
+// workgroup updates -- `group_walkers` walkers of each of `colours` colours (1: a half-step launch, base state
+// ctl.state2; 2: a full-step launch, red then black, the black base one half-step further), starting at walker
+// `group_first` of the shard.  It runs beside the updating wavefronts, so the draw arithmetic is on nobody's
+// critical path; its own chain is kept short by fetching every round's jump entries before anything else (and
+// before the workgroup barrier the updating wavefronts need for their tables, when there is one).
+template <class T, int MAXR>
+__device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const StepCtl* ctl_ptr, bool block_barrier, DrawRec<T>* write0,
+                                               DrawRec<T>* write1, int colours, int shard_begin, int shard_count, int group_first,
+                                               int group_walkers, int lane, bool black_only = false)
 {
+#ifdef MCMCPP_STAMPS
+    unsigned long long dstamp[5] = {0, 0, 0, 0, 0};
+#define MCMCPP_DSTAMP(k, drain)                                                                             \
+    do                                                                                                      \
+    {                                                                                                       \
+        if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+        dstamp[k] = __builtin_amdgcn_s_memrealtime();                                                       \
+    } while (0)
+#else
+#define MCMCPP_DSTAMP(k, drain) \
+    do                          \
+    {                           \
+    } while (0)
+#endif
+    MCMCPP_DSTAMP(0, false);
     const bool direct = a.task_jump != nullptr;
-    const int tasks = 3 * group_walkers;
-    for (int t = lane; t < tasks; t += 64)
+    const int per_colour = 3 * group_walkers;
+    const int tasks = colours * per_colour;
+    const int last = shard_begin + shard_count - 1;
+    Affine128 j_a[MAXR], j_b[MAXR];
+    int wi[MAXR], kk[MAXR], cc[MAXR];
+    bool ok[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
     {
-        const int slot = t / 3, k = t - 3 * slot;
-        if (group_first + slot >= shard_count) continue;
-        const int i = shard_begin + group_first + slot;
-        Affine128 j_a, j_b;
-        if (direct)
-            j_a = a.task_jump[3 * i + k];
-        else
-        {
-            j_a = a.jump_hi[i >> 8];
-            j_b = a.jump_lo[i & 255];
-        }
-        compute_draw<T>(a, ctl.state2, j_a, j_b, direct, k, write_base + i);
+        const int t = lane + 64 * r;
+        cc[r] = t >= per_colour ? 1 : 0;
+        const int tt = t - cc[r] * per_colour;
+        const int slot = tt / 3;
+        kk[r] = tt - 3 * slot;
+        ok[r] = t < tasks && group_first + slot < shard_count;
+        wi[r] = min(shard_begin + group_first + slot, last);  // always a valid table index: the loads are unconditional
+        j_a[r] = *(direct ? a.task_jump + (3 * wi[r] + kk[r]) : a.jump_hi + (wi[r] >> 8));  // branch-free: one pointer, one load
+        j_b[r] = a.jump_lo[direct ? 0 : (wi[r] & 255)];
     }
+    const StepCtl ctl = *ctl_ptr;
+    MCMCPP_DSTAMP(1, true);
+    if (block_barrier) __syncthreads();  // keep the workgroup barrier count whole
+    MCMCPP_DSTAMP(2, false);
+    // black_only: the full-step kernels' second draw wavefront (black records of the next step, with partner2)
+    const bool with_p2 = colours > 1 || black_only;
+    const U128 base1 = with_p2 ? apply(a.half_jump, ctl.state2) : ctl.state2;
+    uint64_t raw[MAXR];
+    bool p2[MAXR];
+    // raw outputs of all rounds; then the partner2 gathers of all rounds go out together, ahead of every store
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+    {
+        const bool blk = black_only || cc[r] != 0;
+        raw[r] = draw_raw<T>(a, blk ? base1 : ctl.state2, j_a[r], j_b[r], direct, kk[r]);
+        p2[r] = ok[r] && with_p2 && blk && kk[r] == 0;
+    }
+    // (the jump entries of this round are spent: their registers take the gathered ones; every lane fetches, lanes
+    //  without a partner draw entry 0)
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+    {
+        const uint32_t jj = p2[r] ? draw_partner<T>(a, raw[r]) : 0u;
+        j_a[r] = *(direct ? a.task_jump + 3 * (size_t)jj : a.jump_hi + (jj >> 8));  // branch-free: one pointer, one load
+        j_b[r] = a.jump_lo[direct ? 0u : (jj & 255u)];
+    }
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+        if (ok[r]) draw_store<T>(a, kk[r], raw[r], (cc[r] ? write1 : write0) + wi[r]);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r)
+        if (p2[r]) ((cc[r] ? write1 : write0) + wi[r])->partner2 = draw_partner2<T>(a, ctl.state2, j_a[r], j_b[r], direct);
+    MCMCPP_DSTAMP(3, false);
+#ifdef MCMCPP_STAMPS
+    if (a.stamps != nullptr && lane == 0 && blockIdx.x < 4096)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (blockIdx.x == 0)
+        {
+            dstamp[4] = __builtin_amdgcn_s_memrealtime();
+            for (int k = 0; k < 5; ++k) a.stamps[8 + 2 * 3 * 4096 + k] = dstamp[k];
+        }
+        a.stamps[8 + (a.pos_parity | a.color) * 3 * 4096 + 2 * 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <class T, class Calc, int EPL, int LPW>
@@ -361,10 +523,8 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     if (wib == kWavesPerBlock)
     {
         // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-        const StepCtl ctl_d = *hot_ctl_in;
-        if (Calc::block_scratch_elems(h_dims) != 0) __syncthreads();  // keep the workgroup barrier count whole
-        draw_wave_body<T>(a, ctl_d, h_draws_next, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * nw,
-                          kWavesPerBlock * nw, lane);
+        draw_wave_body<T, 2>(a, hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0, h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count,
+                             blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -575,7 +735,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
 // draw).  Run by the host for the first two half-steps after set_state / at the start of run(); from then on
 // every half-step launch leaves the records of its colour's next update behind.
 template <class T>
-__global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a, U128 base)
+__global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a, U128 base, U128 red_base, int with_partner2)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 3 * a.shard_count) return;
@@ -590,7 +750,8 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
         j_a = a.jump_hi[i >> 8];
         j_b = a.jump_lo[i & 255];
     }
-    compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + ((size_t)a.draw_parity * 2 + (size_t)a.color) * (size_t)a.n + i);
+    compute_draw<T>(a, base, j_a, j_b, direct, k, a.draws + ((size_t)a.draw_parity * 2 + (size_t)a.color) * (size_t)a.n + i,
+                    with_partner2 != 0, red_base);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -606,6 +767,56 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
 // ---------------------------------------------------------------------------------------------------------
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
 
+constexpr int kMcXS = 34;  // row stride of staged proposals (doubles): even (16-byte rows), = 2 mod 16 to spread LDS banks
+
+// The wavefront's share of P^T, held in registers for the whole launch: for k-step ks, B[k = 4ks + lane/16][n] with
+// tile column n of y0 = matrix column 2n and of y1 = matrix column 2n + 1, so that the product comes back in the
+// very lanes (and element order) that hold the proposal: lane (grp, sub) holds x[2 sub], x[2 sub + 1].
+struct McB
+{
+    double2 b[8];
+};
+__device__ __forceinline__ void mc_load_b(const double* sh_pt, int sub, int grp, McB& B)
+{
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) B.b[ks] = *reinterpret_cast<const double2*>(sh_pt + (4 * ks + grp) * 32 + 2 * sub);
+}
+
+// log-posteriors -1/2 x^T P x of the 4P proposals prop[q] (q < P; row 4q + grp of the tile), one MFMA tile:
+// Y = X * P^T in 8 k-steps, k ascending (the host's fma order), then t_j = x_j * y_j and the canonical tree
+// (in-lane pair, then the 16-lane butterfly).  `sx` is a wave-private staging area of 4P x kMcXS doubles.
+template <int P>
+__device__ __forceinline__ void mc_eval(const McB& B, double* sx, int sub, int grp, int dims, const double (&prop)[P][2], double (&lp)[P])
+{
+#pragma unroll
+    for (int q = 0; q < P; ++q) *reinterpret_cast<double2*>(sx + (4 * q + grp) * kMcXS + 2 * sub) = make_double2(prop[q][0], prop[q][1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double xa[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xa[ks] = (sub < 4 * P) ? sx[sub * kMcXS + 4 * ks + grp] : 0.0;  // A[m = lane%16][k = 4ks + lane/16]
+    mfma_f64x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+    {
+        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], B.b[ks].x, y0, 0, 0, 0);
+        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], B.b[ks].y, y1, 0, 0, 0);
+    }
+    const bool in = 2 * sub < dims;  // D is even: both of the lane's elements or neither
+#pragma unroll
+    for (int r = 0; r < P; ++r)
+    {
+        const double t0 = prop[r][0] * y0[r], t1 = prop[r][1] * y1[r];
+        double t = in ? t0 + t1 : 0.0;
+        t = t + dpp_move<0xB1>(t);
+        t = t + dpp_move<0x4E>(t);
+        t = t + dpp_move<0x141>(t);
+        t = t + dpp_move<0x140>(t);
+        lp[r] = -0.5 * t;
+    }
+}
+
 // P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
 template <class T, class Calc, int EPL, int LPW, int P>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + 1))
@@ -615,7 +826,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
     static_assert(P == 2 || P == 4, "two or four passes");
     constexpr int NW = 4 * P;   // walkers per wavefront
-    constexpr int XS = 33;      // row stride of the staged proposals (doubles): odd, to spread LDS banks
+    constexpr int XS = kMcXS;
     // LDS: [P^T zero-padded to 32 x 32 (workgroup)][proposal rows, NW x XS per wavefront]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* sh_pt = reinterpret_cast<T*>(smem);
@@ -627,6 +838,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     stamp_val[6] = __builtin_amdgcn_s_memrealtime();
 #endif
     MCMCPP_STAMP(0);
+    MCMCPP_STAMP_BLOCK(0);
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
     const bool h_draw_wave = ((hot_bits >> 25) & 1u) != 0;
@@ -645,10 +857,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     if ((threadIdx.x >> 6) == kWavesPerBlock)
     {
         // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-        const StepCtl ctl_d = *hot_ctl_in;
-        __syncthreads();  // the matrix barrier of the updating wavefronts
-        draw_wave_body<T>(a, ctl_d, h_draws_next, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW,
-                          lane);
+        draw_wave_body<T, 2>(a, hot_ctl_in, true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
+                             h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -730,7 +940,9 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
     MCMCPP_STAMP(2);  // next draws done
 
-    // ---- proposals (StretchMove.h:105-108), staged as rows of X ---------------------------------------------------
+    // ---- proposals (StretchMove.h:105-108) -----------------------------------------------------------------------
+    McB matB;
+    mc_load_b(sh_pt, sub, grp, matB);
     T prop[P][2];
 #pragma unroll
     for (int q = 0; q < P; ++q)
@@ -742,45 +954,12 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
             const T zd = rec[q].z * d;
             prop[q][e] = par[q][e] + zd;
         }
-        T* xr = sh_x + (4 * q + grp) * XS + i0;
-        xr[0] = prop[q][0];
-        xr[1] = prop[q][1];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    MCMCPP_STAMP(3);  // partner rows landed, proposals staged
+    MCMCPP_STAMP(3);  // partner rows landed
 
-    // ---- Y = X * P^T on the matrix cores: 8 k-steps x 2 column tiles, k ascending (the host's fma order) ------------
-    mfma_f64x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-    {
-        const double xa = (sub < NW) ? sh_x[sub * XS + 4 * ks + grp] : 0.0;  // A[m = lane%16][k = 4ks + lane/16]
-        const double b0 = sh_pt[(4 * ks + grp) * 32 + sub];                  // B[k = 4ks + lane/16][n = lane%16]
-        const double b1 = sh_pt[(4 * ks + grp) * 32 + 16 + sub];
-        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b0, y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b1, y1, 0, 0, 0);
-    }
-    // t[m][n] = x[m][n] * y[m][n], then the canonical tree over n: tree16(columns 0..15) + tree16(columns 16..31)
+    // ---- Y = X * P^T on the matrix cores, products and the canonical tree ------------------------------------------
     T lp_new[P];
-#pragma unroll
-    for (int r = 0; r < P; ++r)
-    {
-        const int m = 4 * r + grp;
-        const T x0 = sh_x[m * XS + sub], x1 = sh_x[m * XS + 16 + sub];
-        T t0 = (sub < h_dims) ? x0 * y0[r] : (T)0;
-        T t1 = (16 + sub < h_dims) ? x1 * y1[r] : (T)0;
-        t0 = t0 + dpp_move<0xB1>(t0);
-        t1 = t1 + dpp_move<0xB1>(t1);
-        t0 = t0 + dpp_move<0x4E>(t0);
-        t1 = t1 + dpp_move<0x4E>(t1);
-        t0 = t0 + dpp_move<0x141>(t0);
-        t1 = t1 + dpp_move<0x141>(t1);
-        t0 = t0 + dpp_move<0x140>(t0);
-        t1 = t1 + dpp_move<0x140>(t1);
-        lp_new[r] = (T)-0.5 * (t0 + t1);
-    }
+    mc_eval<P>(matB, sh_x, sub, grp, h_dims, prop, lp_new);
     MCMCPP_STAMP(4);  // calculator done
 
     // ---- Metropolis accept in place, chain store, counters ------------------------------------------------------------
@@ -816,6 +995,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
     }
     MCMCPP_STAMP(5);
+    MCMCPP_STAMP_BLOCK(1);
 #ifdef MCMCPP_STAMPS
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
     {

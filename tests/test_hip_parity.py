@@ -19,6 +19,14 @@ from tests.goldens import DIGEST, GOLDEN_DIR, SMALL, Golden
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["full_step", "half_step"])
+def step_path(request, monkeypatch):
+    """run() steps small ensembles with one launch per ensemble step (full_step_kernel.hpp) and large ones with
+    one launch per half-step; the cases that take this fixture are checked on both paths."""
+    monkeypatch.setenv("MCMCPP_HIP_FULL_STEP", "1" if request.param == "full_step" else "0")
+    return request.param
+
+
 def _params_for(calc, D, t, rng):
     if calc == po.CALC_DENSE_GAUSSIAN:
         a = rng.standard_normal((D, D))
@@ -69,7 +77,7 @@ def _run_hip_against_golden(g, **kw):
 
 
 @pytest.mark.parametrize("name", SMALL + DIGEST)
-def test_hip_matches_reference_golden(name):
+def test_hip_matches_reference_golden(name, step_path):
     _run_hip_against_golden(Golden(name))
 
 
@@ -110,7 +118,7 @@ def _assert_same_state(orc, hip):
     (4098, 32, po.CALC_ROSENBROCK, po.F32, 30, 1),       # ragged last wavefront
     (1000, 9, po.CALC_ROSENBROCK, po.F64, 60, 4),
 ])
-def test_hip_equals_oracle_fresh_cases(W, D, calc, dtype, steps, interval):
+def test_hip_equals_oracle_fresh_cases(W, D, calc, dtype, steps, interval, step_path):
     orc, hip = _oracle_and_hip(W, D, calc, dtype, seed=12345, steps=steps, interval=interval)
     oc, oa = orc.run(steps, interval=interval, mode=po.MODE_COUNTER, threads=4)
     hc, ha = hip.run(steps, interval=interval)
@@ -119,7 +127,7 @@ def test_hip_equals_oracle_fresh_cases(W, D, calc, dtype, steps, interval):
     _assert_same_state(orc, hip)
 
 
-def test_two_level_jump_table_with_non_power_of_two_half(monkeypatch):
+def test_two_level_jump_table_with_non_power_of_two_half(monkeypatch, step_path):
     monkeypatch.setenv("MCMCPP_HIP_TASK_TABLE_MB", "0")
     orc, hip = _oracle_and_hip(1000, 9, po.CALC_ROSENBROCK, po.F64, seed=5, steps=0)
     oc, oa = orc.run(40)
@@ -144,7 +152,7 @@ def test_seed_and_stream_are_honoured():
         np.testing.assert_array_equal(ha, oa)
 
 
-def test_resume_reset_and_unsaved_runs_are_seamless():
+def test_resume_reset_and_unsaved_runs_are_seamless(step_path):
     orc, hip = _oracle_and_hip(512, 16, po.CALC_ROSENBROCK, po.F64, seed=3, steps=0)
     oc, oa = orc.run(90)
     c1, a1 = hip.run(20)
@@ -164,9 +172,9 @@ def test_resume_reset_and_unsaved_runs_are_seamless():
 
 
 @pytest.mark.parametrize("W,D", [(4096 + 6, 32), (600, 18), (2048, 26)])
-def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D):
-    """The f64 MFMA variant of the half-step kernel (normally only used for large dense ensembles) against the
-    oracle, including ragged last wavefronts and padded dimensions (17 <= D <= 32, even)."""
+def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D, step_path):
+    """The f64 MFMA variants of the step kernels against the oracle, including ragged last wavefronts and padded
+    dimensions (17 <= D <= 32, even)."""
     monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "0")
     orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, po.F64, seed=77, steps=0)
     oc, oa = orc.run(30, interval=2, mode=po.MODE_COUNTER, threads=4)
@@ -176,7 +184,7 @@ def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D):
     _assert_same_state(orc, hip)
 
 
-def test_checkpoint_and_resume_in_a_new_handle():
+def test_checkpoint_and_resume_in_a_new_handle(step_path):
     """get_state + the number of steps done is a complete checkpoint: a fresh handle resumes the trajectory."""
     orc, hip = _oracle_and_hip(1024, 16, po.CALC_DENSE_GAUSSIAN, po.F64, seed=21, steps=0)
     oc, oa = orc.run(70)
@@ -198,9 +206,14 @@ def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
                 {"MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1", "MCMCPP_HIP_GRAPH_STEPS": "7"},
                 {"MCMCPP_HIP_TASK_TABLE_MB": "0"},                         # two-level jump table (very large ensembles)
                 {"MCMCPP_HIP_TASK_TABLE_MB": "0", "MCMCPP_HIP_PASSES": "8"},
-                {"MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS": "0"}]:             # matrix-core kernel
+                {"MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS": "0"},              # matrix-core kernel
+                {"MCMCPP_HIP_FULL_STEP": "0"},                             # one launch per half-step
+                {"MCMCPP_HIP_FULL_STEP": "0", "MCMCPP_HIP_NO_DRAW_WAVE": "1"},
+                {"MCMCPP_HIP_NO_DRAW_WAVE": "1"},                          # the updating wavefronts make the next draws
+                {"MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS": "-1"},              # generic kernels for the dense target
+                {"MCMCPP_HIP_COPY_STREAM": "1", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1"}]:
         for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS", "MCMCPP_HIP_TASK_TABLE_MB",
-                  "MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS"):
+                  "MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "MCMCPP_HIP_FULL_STEP", "MCMCPP_HIP_NO_DRAW_WAVE", "MCMCPP_HIP_COPY_STREAM"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -217,6 +230,32 @@ def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
             np.testing.assert_array_equal(acc, base[1])
             for a, b in zip(state, base[2]):
                 np.testing.assert_array_equal(a, b)
+
+
+def test_full_step_runs_interleave_with_half_step_calls():
+    """run() (one launch per ensemble step, ping-pong position buffers) leaves everything where the half-step entry
+    points expect it: odd step counts, single steps, half_step_async in between, get_state after each."""
+    W, D = 640, 12
+    orc, hip = _oracle_and_hip(W, D, po.CALC_ROSENBROCK, po.F64, seed=31, steps=0)
+    oc, oa = orc.run(1 + 3 + 2 + 1 + 5)
+    chunks = []
+    c, _ = hip.run(1)
+    chunks.append(c)
+    np.testing.assert_array_equal(hip.get_state()[0], oc[0])
+    c, _ = hip.run(3)
+    chunks.append(c)
+    for _ in range(2):                      # two ensemble steps through the sharded driver's entry point
+        hip.half_step_async(0)
+        hip.half_step_async(1)
+    hip.synchronize()
+    np.testing.assert_array_equal(hip.get_state()[0], oc[5])
+    c, _ = hip.run(1)
+    chunks.append(c)
+    c, a = hip.run(5)
+    chunks.append(c)
+    np.testing.assert_array_equal(np.concatenate(chunks), np.concatenate([oc[:4], oc[6:]]))
+    np.testing.assert_array_equal(a, oa[7:])
+    _assert_same_state(orc, hip)
 
 
 def test_hip_reproduces_reference_own_test_run():
