@@ -422,6 +422,11 @@ public:
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
+        if (full_fn)
+        {
+            hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, d_nacc, W, kRowMovedBit);
+            HIP_TRY(hipGetLastError());
+        }
         enq_step = half_steps >> 1;
         run_step = 0;
         args_red = make_args(0);
@@ -537,7 +542,11 @@ public:
         HIP_TRY(hipStreamSynchronize(stream));
         if (pos) HIP_TRY(hipMemcpy(pos, d_pos, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToHost));
         if (logp) HIP_TRY(hipMemcpy(logp, d_logp, sizeof(T) * (size_t)W, hipMemcpyDeviceToHost));
-        if (n_accept) HIP_TRY(hipMemcpy(n_accept, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
+        if (n_accept)
+        {
+            HIP_TRY(hipMemcpy(n_accept, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
+            for (int w = 0; w < W; ++w) n_accept[w] &= ~kRowMovedBit;  // (the top bit is the full-step kernels' bookkeeping)
+        }
         return MCMCPP_HIP_OK;
     }
 
@@ -569,7 +578,7 @@ public:
             HIP_TRY(hipMemcpy(a.data(), d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
             uint64_t s = 0;
             for (int c = 0; c < 2; ++c)
-                for (int i = 0; i < shard_count; ++i) s += a[(size_t)c * n + shard_begin + i];
+                for (int i = 0; i < shard_count; ++i) s += a[(size_t)c * n + shard_begin + i] & ~kRowMovedBit;
             *accepted = s;
         }
         if (steps) *steps = steps_since_reset;

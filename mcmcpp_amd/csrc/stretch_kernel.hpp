@@ -158,9 +158,21 @@ __device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec
     }
 }
 
-// STREAM: non-temporal stores, for rows that every launch rewrites wholesale (the full-step kernels' `out` buffer):
-// they drain to memory while the kernel runs instead of sitting dirty in L2 until the end-of-kernel write-back,
-// which would lengthen the gap to the next launch (measured: 0.6 us per launch at 16384 x 32).
+// Write-through stores (sc0 sc1: system scope).  What a launch writes with plain stores sits dirty in L2 until the
+// end-of-kernel write-back, which lengthens the gap to the next launch; written through, the data drains while the
+// kernel still runs.  Measured on the full-step kernel at 16384 x 32 (us per launch): plain 6.70, non-temporal 6.52,
+// write-through 6.10, no row stores at all 5.77.
+__device__ __forceinline__ void store_through(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void store_through(double* p, double v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); }
+template <class V16>
+__device__ __forceinline__ void store_through16(void* p, V16 v)
+{
+    static_assert(sizeof(V16) == 16, "a 16-byte vector");
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// STREAM: write-through stores (see store_through), for the full-step kernels' `out` buffer.
 template <class T, int EPL, bool STREAM = false>
 __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, const T (&val)[EPL])
 {
@@ -177,7 +189,7 @@ __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, 
 #pragma unroll
                 for (int k = 0; k < VN; ++k) x[k] = val[v * VN + k];
                 if (STREAM)
-                    __builtin_nontemporal_store(x, reinterpret_cast<VX*>(row + i0 + v * VN));
+                    store_through16(row + i0 + v * VN, x);
                 else
                     *reinterpret_cast<VX*>(row + i0 + v * VN) = x;
             }
@@ -190,7 +202,7 @@ __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, 
             if (i0 + e < D)
             {
                 if (STREAM)
-                    __builtin_nontemporal_store(val[e], row + i0 + e);
+                    store_through(row + i0 + e, val[e]);
                 else
                     row[i0 + e] = val[e];
             }
@@ -317,7 +329,7 @@ __device__ __forceinline__ void draw_store(const HalfStepArgs<T>& a, int k, uint
             rec->zs = lg * a.dims_minus_one;
         }
         else
-            rec->ln_u = lg;
+            rec->ln_u = lg;  // (plain stores: written through, the scattered record fields cost more than they save)
     }
 }
 // Black records made for the full-step kernels: the partner draw of this walker's red partner j (draw 3*j + 0
@@ -693,7 +705,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         if (accept)
         {
             // Walker::jumpToNewPointSwap (Walker/Walker.h:172-179)
-            store_slice<T, EPL>(row, i0, h_dims, vec_ok, prop);
+            store_slice<T, EPL>(row, i0, h_dims, vec_ok, prop);  // (written through: no measurable difference here)
             if (sub == 0)
             {
                 h_logp[w] = lp_new;
@@ -1006,6 +1018,16 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
         a.partials[((size_t)ctl.partial_slot * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
 }
+
+// Before the first full-step launch of a run(): no row of the second position buffer can be trusted (set_state and
+// the half-step kernels only ever touch the first), so every walker is marked "moved" (full_step_kernel.hpp).
+#ifdef MCMCPP_DEFINE_REDUCE_KERNEL
+__global__ void __launch_bounds__(256) mark_rows_moved_kernel(uint32_t* n_accept, int walkers, uint32_t bit)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < walkers) n_accept[w] |= bit;
+}
+#endif
 
 // Sums the per-wavefront accepted counts of the last `count` ensemble steps into RunInfo.accepted_per_step.
 // Runs once after every graph replay (one workgroup per step); `ctl_after` is the control record the
