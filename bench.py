@@ -12,10 +12,11 @@ resident in HBM).  For N > 1 every rank runs its own independent chain of the sa
 divided by the slowest rank's time.
 
 The JSON line also carries
-  roofline      achieved HBM bytes/s of the dominant kernel: algorithmic bytes per half-step launch
-                ((2D+1)*8 read + (D+1)*8 written per walker update = 784 B at D = 32, x 8192
-                walkers per launch) / the average launch duration measured with HIP events on the launch
-                stream around the replayed launches (mcmcpp_hip_last_run_timing)
+  roofline      achieved HBM bytes/s of the dominant kernel: algorithmic bytes per step-kernel launch
+                ((2D+1)*8 read + (D+1)*8 written per walker update = 784 B at D = 32, x the
+                walker updates one launch performs: all 16 384 with the full-step kernel this workload takes,
+                8 192 with the half-step kernels) / the average launch duration measured with HIP events on
+                the launch stream around the replayed launches (mcmcpp_hip_last_run_timing)
   cpu_baseline  the reference itself (oracle/_ref, kind "reference") or the oracle ("port") timed on this
                 host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
 """
