@@ -53,6 +53,27 @@ __device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const S
 // hot_bits of the full-step kernels: HotBits::pack(...) | pos_parity << 26
 __host__ __device__ inline uint32_t full_step_bits(uint32_t half_bits, int pos_parity) { return half_bits | ((uint32_t)pos_parity << 26); }
 
+// Stored steps reach the host without a copy engine and without a gap in the launch sequence: every launch forwards
+// 1/interval of the most recent stored step from the device chain ring to its twin in pinned host memory (one
+// 16-byte piece per lane, spread over the first draw wavefront of every workgroup, written through so that the
+// PCIe traffic leaves while the kernel is still busy; measured: up to ~64 KB per launch are free, a separate copy
+// of the 4 MiB step costs 75 us of the launch stream).  Stored step k is complete in host memory when ensemble step
+// (k + 2) * interval - 1 has finished; the host copies the run's last stored step itself.
+__device__ __forceinline__ void trickle_stored_step(const RunInfo& run, const StepCtl& ctl, int lane)
+{
+    const long long prev = run.chain_slot_base + ctl.chain_slot - 1;  // the stored step before the one this interval ends with
+    if (run.stage == nullptr || prev < 0) return;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const size_t slot_off = (size_t)(prev & run.slot_mask) * (size_t)run.step_bytes;
+    const size_t begin = (size_t)ctl.save_phase * (size_t)run.slice_bytes;
+    size_t end = begin + (size_t)run.slice_bytes;
+    if (end > (size_t)run.step_bytes) end = (size_t)run.step_bytes;
+    const char* src = static_cast<const char*>(run.chain) + slot_off;
+    char* dst = static_cast<char*>(run.stage) + slot_off;
+    for (size_t off = begin + ((size_t)blockIdx.x * 64 + (size_t)lane) * 16; off < end; off += (size_t)gridDim.x * 64 * 16)
+        store_through16(dst + off, *reinterpret_cast<const v4u*>(src + off));
+}
+
 // the workgroup's extra wavefronts: the draws of the NEXT ensemble step of every walker this workgroup updates
 // (`wpb` of each colour, starting at walker blockIdx.x * wpb); extra wavefronts 0, 1 make the red records of the first
 // and second half of those walkers, 2 and 3 the black ones
@@ -62,6 +83,7 @@ __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, co
 {
     const int black = which >> 1, half = which & 1;
     const int h0 = (wpb + 1) / 2;  // walkers of the first half
+    if (which == 0) trickle_stored_step(*a.run, *ctl_ptr, lane);
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
     draw_wave_body<T, 1>(a, ctl_ptr, block_barrier, dst, dst, 1, 0, n, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0);
 }
@@ -161,11 +183,13 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     if (!wave_active) return;
 
     long long save_slot = -1;
-    if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = run.chain_slot_base + ctl.chain_slot;
+    if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;
 
     if (!h_draw_wave)
     {
-        // no extra wavefronts (many walkers per wavefront): the next step's draws of this wavefront's walkers, here
+        // no extra wavefronts (many walkers per wavefront): the stored-step forwarding and the next step's draws of this
+        // wavefront's walkers happen here
+        if (wib == 0) trickle_stored_step(run, ctl, lane);
         const bool direct = a.task_jump != nullptr;
         const U128 base_b = apply(a.half_jump, ctl.state2);
         for (int t = lane; t < 6 * WPP; t += 64)
@@ -387,7 +411,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     warm_launch_args<T>();  // (its wait overlaps the second round trip)
     if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run);
     long long save_slot = -1;
-    if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = run.chain_slot_base + ctl.chain_slot;
+    if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;
 
     // accept test of walker slot q; fin = row afterwards
     auto decide = [&](int q, const T (&own)[2], const T (&prop)[2], const DrawRec<T>& rec, T lp_old, T lp_new, bool count_ties, T (&fin)[2], T& lp_fin) -> bool {

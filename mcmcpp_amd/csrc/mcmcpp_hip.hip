@@ -20,6 +20,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mcmcpp_hip.h"
@@ -51,6 +52,30 @@ Affine128 compose(const Affine128& g, const Affine128& f)  // g after f
     r.mult = mul128(g.mult, f.mult);
     r.plus = add128(mul128(g.mult, f.plus), g.plus);
     return r;
+}
+
+// memcpy of a large block split over a few threads (the un-overlapped tail of a run's chain download: a single core
+// moves ~12 GB/s into pageable memory)
+void parallel_memcpy(char* dst, const char* src, size_t bytes)
+{
+    const size_t kMinPiece = 512u << 10;
+    int pieces = (int)(bytes / kMinPiece);
+    if (pieces > 4) pieces = 4;
+    if (pieces < 2)
+    {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t piece = ((bytes / (size_t)pieces) + 63) & ~(size_t)63;
+    std::thread helpers[3];
+    for (int k = 1; k < pieces; ++k)
+    {
+        const size_t off = piece * (size_t)k;
+        const size_t len = (k == pieces - 1) ? bytes - off : piece;
+        helpers[k - 1] = std::thread([=]() { std::memcpy(dst + off, src + off, len); });
+    }
+    std::memcpy(dst, src, piece);
+    for (int k = 1; k < pieces; ++k) helpers[k - 1].join();
 }
 
 long env_long(const char* name, long fallback)
@@ -417,7 +442,22 @@ public:
             if (sub_saved > eighth) sub_saved = eighth;
             if (sub_saved < 1) sub_saved = 1;
         }
-        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, chain_out ? step_bytes * (size_t)sub_saved : 0);
+        // Full-step kernels forward stored steps to pinned host memory themselves (trickle_stored_step): a ring of
+        // `ring` slots on the device with a twin in pinned host memory, no copy engine, no gap in the launch sequence.
+        const bool trickle = full_fn && chain_out && step_bytes % 16 == 0 && env_long("MCMCPP_HIP_TRICKLE", 1) != 0;
+        int64_t ring = 0, chunk_steps = 0;
+        if (trickle)
+        {
+            ring = 4;
+            while (ring < 64 && (size_t)(2 * ring) * step_bytes <= 2 * chain_subchunk_bytes) ring *= 2;
+            // the host enqueues one chunk ahead of the one it waits for: stored steps of two chunks are in flight
+            int64_t per_chunk = (graph_steps > 0 ? graph_steps : 64) / (int64_t)interval;
+            if (per_chunk > (ring - 2) / 2) per_chunk = (ring - 2) / 2;
+            if (per_chunk < 1) per_chunk = 1;
+            chunk_steps = per_chunk * interval;
+        }
+        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved : 0,
+                                    trickle ? step_bytes * (size_t)ring : 0);
         if (rc) return rc;
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
@@ -435,8 +475,13 @@ public:
         if (rc) return rc;
 
         const auto tp1 = std::chrono::steady_clock::now();
-        const int64_t n_sub = (n_saved + sub_saved - 1) / sub_saved;
-        double launch_ms = 0.0;  // GPU time of the half-step launches alone (downloads excluded)
+        double launch_ms = 0.0;  // GPU time of the step launches alone (downloads excluded)
+        if (trickle)
+        {
+            rc = run_trickle(n_saved, interval, (char*)chain_out, accepted_per_step != nullptr, step_bytes, ring, chunk_steps, &launch_ms);
+            sub_saved = n_saved + 1;  // (the sub-chunk loop below has nothing to do)
+        }
+        const int64_t n_sub = trickle ? 0 : (n_saved + sub_saved - 1) / sub_saved;
         int64_t pending_first = -1, pending_count = 0;  // sub-chunk whose staging still has to reach chain_out
         int pending_buf = 0;
         for (int64_t c = 0; c < n_sub && rc == MCMCPP_HIP_OK; ++c)
@@ -445,10 +490,15 @@ public:
             const int64_t first = c * sub_saved;
             const int64_t now = (n_saved - first < sub_saved) ? n_saved - first : sub_saved;
             RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256 + 64 * (c % 4));
+            static_assert(sizeof(RunInfo) <= 64, "the pinned upload slots are 64 bytes apart");
             ri->chain = chain_out ? d_chain[buf] : nullptr;
             ri->accepted_per_step = accepted_per_step ? d_acc : nullptr;
             ri->interval = interval;
             ri->chain_slot_base = -first;
+            ri->stage = nullptr;
+            ri->slot_mask = -1;
+            ri->slice_bytes = 0;
+            ri->step_bytes = (int64_t)step_bytes;
             HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
             // the events of slot c%4 were last used by sub-chunk c-4, which has long been waited for
             HIP_TRY(hipEventRecord(ev_t0[c & 3], stream));
@@ -534,6 +584,87 @@ public:
                          us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4), last_ms * 1e3);
         }
         return rc;
+    }
+
+    // The chain path of the full-step kernels.  Stored step k is complete in the pinned ring when ensemble step
+    // (k + 2) * interval - 1 has finished (every launch forwards 1/interval of the previous stored step), and its
+    // ring slot is overwritten from step (k + ring + 1) * interval on: the host enqueues chunks of steps, stays one
+    // chunk ahead of the one it waits for, copies out whatever has become complete and never lets the launches
+    // run into a slot it has not copied yet.  The run's last stored step has no launches behind it: it is copied
+    // from the device ring at the end.
+    int run_trickle(int64_t n_saved, int32_t interval, char* chain_out, bool want_accepted, size_t step_bytes, int64_t ring,
+                    int64_t chunk_steps, double* launch_ms)
+    {
+        const int64_t total = n_saved * (int64_t)interval;
+        RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256);
+        ri->chain = d_ring;
+        ri->accepted_per_step = want_accepted ? d_acc : nullptr;
+        ri->interval = interval;
+        ri->chain_slot_base = 0;
+        ri->stage = h_ring;
+        ri->slot_mask = ring - 1;
+        ri->slice_bytes = (int64_t)(((step_bytes + (size_t)interval - 1) / (size_t)interval + 15) / 16 * 16);
+        ri->step_bytes = (int64_t)step_bytes;
+        HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+
+        int64_t enq = 0, copied = 0;       // ensemble steps enqueued; stored steps handed to the caller
+        int64_t chunk_end[4] = {0, 0, 0, 0};
+        int64_t next_chunk = 0, oldest = 0;  // chunks enqueued / chunks whose completion has been processed
+        auto process_oldest = [&]() -> int {
+            const int e = (int)(oldest & 3);
+            float ms = 0.f;
+            HIP_TRY(hipEventSynchronize(ev_t1[e]));
+            HIP_TRY(hipEventElapsedTime(&ms, ev_t0[e], ev_t1[e]));
+            *launch_ms += ms;
+            const int64_t complete = chunk_end[e] / interval - 1;  // stored steps fully forwarded by now
+            for (; copied < complete; ++copied)
+            {
+                char* dst = chain_out + step_bytes * (size_t)copied;
+                const char* src = (char*)h_ring + step_bytes * (size_t)(copied & (ring - 1));
+                if (enq == total)
+                    parallel_memcpy(dst, src, step_bytes);  // nothing left to overlap with: be quick
+                else
+                    std::memcpy(dst, src, step_bytes);
+            }
+            ++oldest;
+            return MCMCPP_HIP_OK;
+        };
+        while (enq < total)
+        {
+            const int64_t now = (total - enq < chunk_steps) ? total - enq : chunk_steps;
+            // at most two chunks in flight, and no launch may forward into a ring slot that is still to be copied out
+            while (next_chunk > oldest && (next_chunk - oldest >= 2 || enq + now > (copied + ring + 1) * (int64_t)interval))
+            {
+                const int rc = process_oldest();
+                if (rc) return rc;
+            }
+            const int e = (int)(next_chunk & 3);
+            HIP_TRY(hipEventRecord(ev_t0[e], stream));
+            const int rc = enqueue_steps(now);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_t1[e], stream));
+            enq += now;
+            chunk_end[e] = enq;
+            ++next_chunk;
+        }
+        // What the launches do not forward: the run's last stored step.  Its download is queued now, behind the last
+        // launch, so that it runs while the host still copies out the steps before it.
+        {
+            const size_t off = step_bytes * (size_t)((n_saved - 1) & (ring - 1));
+            HIP_TRY(hipMemcpyAsync((char*)h_ring + off, (char*)d_ring + off, step_bytes, hipMemcpyDeviceToHost, stream));
+        }
+        while (next_chunk > oldest)
+        {
+            const int rc = process_oldest();
+            if (rc) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (; copied < n_saved; ++copied)  // (exactly one: every earlier one has been forwarded and copied above)
+        {
+            const size_t off = step_bytes * (size_t)(copied & (ring - 1));
+            parallel_memcpy(chain_out + step_bytes * (size_t)copied, (char*)h_ring + off, step_bytes);
+        }
+        return MCMCPP_HIP_OK;
     }
 
     int get_state(void* pos, void* logp, uint32_t* n_accept) override
@@ -686,6 +817,10 @@ private:
         ri.accepted_per_step = nullptr;
         ri.interval = 1;
         ri.chain_slot_base = 0;
+        ri.stage = nullptr;
+        ri.slot_mask = -1;
+        ri.slice_bytes = 0;
+        ri.step_bytes = 0;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(d_run, &ri, sizeof ri, hipMemcpyHostToDevice));
         return MCMCPP_HIP_OK;
@@ -880,8 +1015,21 @@ private:
 
     // persistent per-run buffers, grown on demand: per-step accepted counters, the two halves of the device
     // chain and their pinned staging twins
-    int ensure_run_buffers(size_t acc_entries, size_t half_bytes)
+    int ensure_run_buffers(size_t acc_entries, size_t half_bytes, size_t ring_bytes)
     {
+        if (ring_bytes > ring_capacity)
+        {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (d_ring) hipFree(d_ring);
+            if (h_ring) hipHostFree(h_ring);
+            d_ring = nullptr;
+            h_ring = nullptr;
+            ring_capacity = 0;
+            if (hipMalloc(&d_ring, ring_bytes) != hipSuccess) return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of device chain", ring_bytes);
+            if (hipHostMalloc(&h_ring, ring_bytes, hipHostMallocDefault) != hipSuccess)
+                return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of pinned staging", ring_bytes);
+            ring_capacity = ring_bytes;
+        }
         if (acc_entries > acc_capacity)
         {
             if (d_acc) hipFree(d_acc);
@@ -945,6 +1093,8 @@ private:
             if (ev_copied[k]) hipEventDestroy(ev_copied[k]);
             if (ev_filled[k]) hipEventDestroy(ev_filled[k]);
         }
+        if (d_ring) hipFree(d_ring);
+        if (h_ring) hipHostFree(h_ring);
         if (d_params) hipFree(d_params);
         if (d_params_padded) hipFree(d_params_padded);
         if (d_jump_lo) hipFree(d_jump_lo);
@@ -976,6 +1126,8 @@ private:
     int shard_begin = 0, shard_count = 0, device = -1, graph_steps = 32;
     size_t chain_subchunk_bytes = 0, chain_half_capacity = 0, acc_capacity = 0;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_filled[2] = {nullptr, nullptr};
+    void *d_ring = nullptr, *h_ring = nullptr;  // full-step chain path: device ring of stored steps and its pinned host twin
+    size_t ring_capacity = 0;
     hipStream_t copy_stream = nullptr;  // experiment (MCMCPP_HIP_COPY_STREAM=1): chain downloads beside the launches
     T* d_chain[2] = {nullptr, nullptr};
     void* h_stage[2] = {nullptr, nullptr};

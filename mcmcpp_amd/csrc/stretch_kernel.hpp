@@ -54,6 +54,12 @@ struct RunInfo
     uint32_t* accepted_per_step; // device counters [steps of this run] or nullptr
     int64_t interval;            // store the last step of every `interval`
     int64_t chain_slot_base;     // slot of the first stored step of this run
+    // full-step kernels: the device chain is a ring of slot_mask + 1 slots and every launch forwards a slice of the
+    // most recent stored step to its twin in pinned host memory (trickle_stored_step); nullptr: no forwarding
+    void* stage;
+    int64_t slot_mask;           // stored step k lives in slot k & slot_mask (all ones: slots are not reused)
+    int64_t slice_bytes;         // bytes of a stored step forwarded per launch (a multiple of 16)
+    int64_t step_bytes;          // W * D * sizeof(T) (a multiple of 16 when stage != nullptr)
 };
 
 // The random part of one stretch-move update, computed one update ahead (StretchMove.h:102,104,110,113).

@@ -211,9 +211,12 @@ def test_wave_mapping_and_chunking_do_not_change_results(monkeypatch):
                 {"MCMCPP_HIP_FULL_STEP": "0", "MCMCPP_HIP_NO_DRAW_WAVE": "1"},
                 {"MCMCPP_HIP_NO_DRAW_WAVE": "1"},                          # the updating wavefronts make the next draws
                 {"MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS": "-1"},              # generic kernels for the dense target
-                {"MCMCPP_HIP_COPY_STREAM": "1", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1"}]:
+                {"MCMCPP_HIP_COPY_STREAM": "1", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1", "MCMCPP_HIP_TRICKLE": "0"},
+                {"MCMCPP_HIP_TRICKLE": "0"},                               # stored steps by device-to-host copies
+                {"MCMCPP_HIP_CHAIN_SUBCHUNK_MB": "1"}]:                    # the smallest ring of stored steps
         for k in ("MCMCPP_HIP_PASSES", "MCMCPP_HIP_CHAIN_SUBCHUNK_MB", "MCMCPP_HIP_GRAPH_STEPS", "MCMCPP_HIP_TASK_TABLE_MB",
-                  "MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "MCMCPP_HIP_FULL_STEP", "MCMCPP_HIP_NO_DRAW_WAVE", "MCMCPP_HIP_COPY_STREAM"):
+                  "MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "MCMCPP_HIP_FULL_STEP", "MCMCPP_HIP_NO_DRAW_WAVE", "MCMCPP_HIP_COPY_STREAM",
+                  "MCMCPP_HIP_TRICKLE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -255,6 +258,26 @@ def test_full_step_runs_interleave_with_half_step_calls():
     chunks.append(c)
     np.testing.assert_array_equal(np.concatenate(chunks), np.concatenate([oc[:4], oc[6:]]))
     np.testing.assert_array_equal(a, oa[7:])
+    _assert_same_state(orc, hip)
+
+
+@pytest.mark.parametrize("W,D,dtype,interval,n_saved", [
+    (2048, 32, po.F64, 1, 40),      # every step stored: each launch forwards a whole step
+    (2048, 32, po.F64, 3, 11),
+    (1000, 9, po.F64, 7, 5),        # 72 000-byte steps, slices that do not divide them
+    (518, 5, po.F32, 2, 9),         # 10 360-byte steps (a multiple of 8, not of 16): the copy-engine path
+    (512, 16, po.F32, 50, 1),       # a single stored step: nothing to forward
+    (4096, 32, po.F64, 100, 3),
+])
+def test_stored_steps_forwarded_by_the_launches(W, D, dtype, interval, n_saved):
+    """The chain path of the full-step kernels (trickle_stored_step): every stored step arrives intact whatever the
+    slicing interval, ring size and run length."""
+    orc, hip = _oracle_and_hip(W, D, po.CALC_ROSENBROCK, dtype, seed=8, steps=0)
+    for part in (n_saved, 2):       # a second, short run on the same handle
+        oc, oa = orc.run(part, interval=interval, mode=po.MODE_COUNTER, threads=4)
+        hc, ha = hip.run(part, interval=interval)
+        np.testing.assert_array_equal(hc, oc)
+        np.testing.assert_array_equal(ha, oa)
     _assert_same_state(orc, hip)
 
 
