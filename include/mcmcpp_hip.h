@@ -173,6 +173,27 @@ void* mcmcpp_hip_device_positions(mcmcpp_hip_sampler* h);
 int mcmcpp_hip_shard_span(mcmcpp_hip_sampler* h, int32_t color, int64_t* offset_elems, int64_t* count_elems);
 int mcmcpp_hip_synchronize(mcmcpp_hip_sampler* h);
 
+/* ---- chain analysis on the device -------------------------------------------- */
+
+/* Analysis::CovarianceMatrix (reference MCMCpp/Analysis/CovarianceMatrix.h:154-257): mean, covariance and
+ * correlation matrix of stored chain steps.  The sums  s_i = sum x_i,  S_ij = sum x_i x_j  over all samples are a
+ * rank-N update X^T X and run on the matrix cores (fp64 accumulation for both element types); the slicing the
+ * reference's calculateCovar(start, end, sliceInterval) does while iterating is expressed by step_stride.
+ *   create      dtype MCMCPP_HIP_F64 / _F32 = the chain's ParamType; device -1 = current
+ *   add_steps   n_steps stored steps of num_walkers*num_params elements each (host memory), consecutive ones
+ *               step_stride steps apart; may be called repeatedly (chain blocks, several chains)
+ *   finish      CovarianceMatrix::finalizeMatrix: mean[D], cov[D*D], corr[D*D] in the chain's element type (any may
+ *               be NULL); *num_points = samples used.  The accumulator keeps its sums: more steps may follow.
+ * The reference's sequential Kahan sums cannot be kept by a parallel sum: results agree with it to rounding
+ * (tests/test_moments.py states the tolerance), not bit for bit. */
+typedef struct mcmcpp_hip_moments mcmcpp_hip_moments;
+int mcmcpp_hip_moments_create(int32_t dtype, int32_t device, int32_t num_walkers, int32_t num_params, mcmcpp_hip_moments** out);
+void mcmcpp_hip_moments_destroy(mcmcpp_hip_moments* m);
+int mcmcpp_hip_moments_reset(mcmcpp_hip_moments* m);
+int mcmcpp_hip_moments_add_steps(mcmcpp_hip_moments* m, const void* steps, int64_t n_steps, int64_t step_stride);
+int mcmcpp_hip_moments_finish(mcmcpp_hip_moments* m, int64_t* num_points, void* mean, void* cov, void* corr);
+const char* mcmcpp_hip_moments_last_error(const mcmcpp_hip_moments* m);
+
 int mcmcpp_hip_abi_version(void);
 
 #ifdef __cplusplus

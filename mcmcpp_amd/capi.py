@@ -19,6 +19,8 @@ EXPORTS = [
     "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing",
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
+    "mcmcpp_hip_moments_create", "mcmcpp_hip_moments_destroy", "mcmcpp_hip_moments_reset", "mcmcpp_hip_moments_add_steps",
+    "mcmcpp_hip_moments_finish", "mcmcpp_hip_moments_last_error",
 ]
 
 
@@ -81,6 +83,14 @@ def lib():
         L.mcmcpp_hip_device_positions.restype = vp
         L.mcmcpp_hip_shard_span.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
         L.mcmcpp_hip_synchronize.argtypes = [vp]
+        L.mcmcpp_hip_moments_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+        L.mcmcpp_hip_moments_destroy.argtypes = [vp]
+        L.mcmcpp_hip_moments_destroy.restype = None
+        L.mcmcpp_hip_moments_reset.argtypes = [vp]
+        L.mcmcpp_hip_moments_add_steps.argtypes = [vp, vp, i64, i64]
+        L.mcmcpp_hip_moments_finish.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
+        L.mcmcpp_hip_moments_last_error.argtypes = [vp]
+        L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -188,3 +198,46 @@ class HipSampler:
 
     def synchronize(self):
         self._check(lib().mcmcpp_hip_synchronize(self.h))
+
+
+class HipMoments:
+    """Device-side Analysis::CovarianceMatrix (include/mcmcpp_hip.h, mcmcpp_hip_moments_*)."""
+
+    def __init__(self, num_walkers, num_params, dtype=F64, device=-1):
+        self.W, self.D, self.dtype = num_walkers, num_params, dtype
+        self.h = C.c_void_p()
+        rc = lib().mcmcpp_hip_moments_create(dtype, device, num_walkers, num_params, C.byref(self.h))
+        if rc != OK:
+            raise HipError(rc, (lib().mcmcpp_hip_moments_last_error(None) or b"").decode())
+
+    def _check(self, rc):
+        if rc != OK:
+            raise HipError(rc, (lib().mcmcpp_hip_moments_last_error(self.h) or b"").decode())
+
+    def add_steps(self, steps, slice_interval=1):
+        """steps[(n, W, D)] (C-contiguous); every slice_interval-th step is used, starting with the first."""
+        steps = np.ascontiguousarray(steps, dtype=np_dtype(self.dtype))
+        assert steps.ndim == 3 and steps.shape[1:] == (self.W, self.D)
+        used = (steps.shape[0] + slice_interval - 1) // slice_interval
+        self._check(lib().mcmcpp_hip_moments_add_steps(self.h, _ptr(steps), used, slice_interval))
+
+    def finish(self):
+        t = np_dtype(self.dtype)
+        mean, cov, corr = np.zeros(self.D, t), np.zeros((self.D, self.D), t), np.zeros((self.D, self.D), t)
+        n = C.c_int64(0)
+        self._check(lib().mcmcpp_hip_moments_finish(self.h, C.byref(n), _ptr(mean), _ptr(cov), _ptr(corr)))
+        return n.value, mean, cov, corr
+
+    def reset(self):
+        self._check(lib().mcmcpp_hip_moments_reset(self.h))
+
+    def close(self):
+        if self.h:
+            lib().mcmcpp_hip_moments_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

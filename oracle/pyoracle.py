@@ -69,6 +69,8 @@ def lib():
             getattr(L, f).restype = C.c_uint64
         L.so_half_step_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
         L.so_half_step_commit.argtypes = [C.c_void_p]
+        L.so_chain_covariance.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
         L.so_positions_ptr.argtypes = [C.c_void_p]
         L.so_positions_ptr.restype = C.c_void_p
         L.so_logp_ptr.argtypes = [C.c_void_p]
@@ -226,6 +228,7 @@ def ref_lib():
         R.ref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
                               C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        R.ref_chain_covariance.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_skewed_initial_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
         R.ref_skewed_initial_values.restype = None
         _ref = R
@@ -257,6 +260,33 @@ def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_cal
         raise ValueError("ref_run failed: %d" % rc)
     return dict(chain=chain, accepted=acc, total=tot, stored=stored.value, seconds=secs.value,
                 fraction=frac.value, chain_full=(rc == 1))
+
+
+def chain_covariance(steps, slice_interval=1):
+    """Analysis::CovarianceMatrix restated (oracle): steps[(n, W, D)] -> (mean[D], cov[D, D], corr[D, D])."""
+    steps = np.ascontiguousarray(steps)
+    dtype = F64 if steps.dtype == np.float64 else F32
+    n, W, D = steps.shape
+    mean = np.zeros(D, steps.dtype)
+    cov = np.zeros((D, D), steps.dtype)
+    corr = np.zeros((D, D), steps.dtype)
+    rc = lib().so_chain_covariance(dtype, _ptr(steps), n, W, D, slice_interval, _ptr(mean), _ptr(cov), _ptr(corr))
+    if rc:
+        raise ValueError("so_chain_covariance failed: %d" % rc)
+    return mean, cov, corr
+
+
+def reference_chain_covariance(steps, slice_interval=1):
+    """The reference's own Analysis::CovarianceMatrix over its own Chain holding `steps`: (cov, corr)."""
+    steps = np.ascontiguousarray(steps)
+    dtype = F64 if steps.dtype == np.float64 else F32
+    n, W, D = steps.shape
+    cov = np.zeros((D, D), steps.dtype)
+    corr = np.zeros((D, D), steps.dtype)
+    rc = ref_lib().ref_chain_covariance(dtype, _ptr(steps), n, W, D, slice_interval, _ptr(cov), _ptr(corr))
+    if rc:
+        raise ValueError("ref_chain_covariance failed: %d" % rc)
+    return cov, corr
 
 
 def reference_skewed_initial_values(W=320, eps=0.13, extra_run_number=53):

@@ -24,6 +24,7 @@ using arrow_vendored::pcg64;
 #include "Movers/StretchMove.h"
 #include "ParallelEnsembleSampler.h"
 #include "Common/SkewedGaussian.h"
+#include "Analysis/CovarianceMatrix.h"
 
 #include "../include/MCMCpp/Device/Calculators.h"
 
@@ -123,6 +124,28 @@ int dispatch(int calcId, int threads, int alphaCode, int W, int D, const T* para
     }
 #undef MCMCPP_REF_GO
 }
+/* The reference's Analysis::CovarianceMatrix over a chain given as [n_steps][W][D]: the steps are put into a
+ * reference Chain (Chain::storeWalker / incrementChainStep, as the Walkers do) and walked with its own iterators. */
+template <class T>
+static int refCovariance(const T* steps, long long n_steps, int W, int D, int slice, T* cov, T* corr)
+{
+    MCMC::Chain::Chain<T> chain(W, D, static_cast<unsigned long long>(n_steps + 1) * W * D * sizeof(T) + (1ull << 20));
+    for (long long s = 0; s < n_steps; ++s)
+    {
+        for (int w = 0; w < W; ++w) chain.storeWalker(w, const_cast<T*>(steps + (static_cast<size_t>(s) * W + w) * D));
+        chain.incrementChainStep();
+    }
+    MCMC::Analysis::CovarianceMatrix<T> cm(D, W);
+    cm.calculateCovar(chain.getStepIteratorBegin(), chain.getStepIteratorEnd(), slice);
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j)
+        {
+            cov[static_cast<size_t>(i) * D + j] = cm.getCovarianceMatrixElement(i, j);
+            corr[static_cast<size_t>(i) * D + j] = cm.getCorrelationMatrixElement(i, j);
+        }
+    return 0;
+}
+
 }  // namespace
 
 extern "C"
@@ -146,6 +169,13 @@ int ref_run(int dtype, int threads, int alpha_code, int W, int D, int calc_id, c
                            static_cast<const float*>(init_pos), static_cast<const float*>(init_logp), n_calls,
                            steps_per_call, slicing, static_cast<float*>(chain_out), chain_capacity_steps,
                            accepted_after_call, total_after_call, stored_steps, seconds, fraction);
+}
+
+int ref_chain_covariance(int dtype, const void* steps, long long n_steps, int W, int D, int slice, void* cov, void* corr)
+{
+    if (dtype == 0)
+        return refCovariance<double>(static_cast<const double*>(steps), n_steps, W, D, slice, static_cast<double*>(cov), static_cast<double*>(corr));
+    return refCovariance<float>(static_cast<const float*>(steps), n_steps, W, D, slice, static_cast<float*>(cov), static_cast<float*>(corr));
 }
 
 /* Initial walker placement of the reference's SkewedGaussian/StretchMove test

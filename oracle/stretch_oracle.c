@@ -303,6 +303,19 @@ uint64_t so_half_steps_done(const so_sampler* s) { return s ? s->half_steps : 0;
 uint64_t so_near_ties(const so_sampler* s) { return s ? s->near_ties : 0; }
 uint64_t so_redraws(const so_sampler* s) { return s ? s->redraws : 0; }
 
+int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32_t walkers, int32_t dims, int32_t slice,
+                        void* mean, void* cov, void* corr)
+{
+    if (!steps || !cov || !corr || n_steps < 1 || walkers < 1 || dims < 1 || slice < 1) return -1;
+    if (dtype == SO_F64)
+        chain_covariance_f64((const double*)steps, n_steps, walkers, dims, slice, (double*)mean, (double*)cov, (double*)corr);
+    else if (dtype == SO_F32)
+        chain_covariance_f32((const float*)steps, n_steps, walkers, dims, slice, (float*)mean, (float*)cov, (float*)corr);
+    else
+        return -1;
+    return 0;
+}
+
 int so_calc_logp(const so_config* cfg, const void* x, void* out)
 {
     int rc = check_cfg(cfg);

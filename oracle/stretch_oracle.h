@@ -12,6 +12,7 @@
  *   MCMCpp/Utility/GwDistribution.h:45-58      z = ((sqrt(a)-1/sqrt(a))*u + 1/sqrt(a))^2, a = 2
  *   MCMCpp/Walker/Walker.h:105,162-179         accept / stay bookkeeping, optional chain store
  *   MCMCpp/Chain/ChainBlock.h:125-131          chain cell layout  step*W*D + walker*D + p
+ *   MCMCpp/Analysis/CovarianceMatrix.h:154-257 covariance / correlation of the stored samples (next row f2)
  *   imneme/pcg-cpp (un-vendored submodule, version unpinned by .gitmodules) pcg64 =
  *     setseq_xsl_rr_128_64: restated from the published algorithm (128-bit LCG, XSL-RR output,
  *     Brown's O(log n) jump-ahead); libstdc++ 11 generate_canonical / exponential_distribution
@@ -99,6 +100,11 @@ uint64_t so_redraws(const so_sampler* s);
 
 /* evaluate a calculator on one D-vector (used to build initial logp arrays in tests and bench) */
 int so_calc_logp(const so_config* cfg, const void* x, void* out);
+
+/* --- next row f2: Analysis::CovarianceMatrix (MCMCpp/Analysis/CovarianceMatrix.h:154-224) over stored steps
+ * [n_steps][walkers][dims], every `slice`-th step; cov and corr are [dims][dims], mean [dims] (may be NULL) */
+int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32_t walkers, int32_t dims, int32_t slice,
+                        void* mean, void* cov, void* corr);
 
 /* --- pcg64 (setseq_xsl_rr_128_64) primitives, exposed for known-answer tests ------------------- */
 typedef struct so_pcg64 {

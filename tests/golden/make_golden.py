@@ -137,6 +137,30 @@ def make_reference_test_run():
     return out
 
 
+def make_covariance():
+    """Analysis::CovarianceMatrix of the reference (its own Chain, its own iterators) over chains produced by the
+    reference's sampler: covariance_<case>.npz holds the chain steps, the slicing and the reference's matrices."""
+    out = []
+    for name, (src, dtype, first, count, slice_interval) in {
+            "covariance_dense96x16": ("dense96x16", po.F64, 60, 48, 1),
+            "covariance_dense96x16_slice5": ("dense96x16", po.F64, 20, 121, 5),
+            "covariance_rosen80x8": ("rosen80x8", po.F64, 100, 90, 3),
+            "covariance_dense80x5_f32": ("dense80x5_f32", po.F32, 50, 100, 2)}.items():
+        c = CASES[src]
+        t = po.np_dtype(dtype)
+        W, D = c["W"], c["D"]
+        params = ar1_precision(D, c["rho"], t).ravel() if "rho" in c else (np.array(c["params"], dtype=t) if "params" in c else None)
+        pos = po.init_positions(dtype, W, D, salt=3)
+        logp = po.Oracle(W, D, c["calc"], params, dtype=dtype).logp(pos)
+        ref = po.reference_run(W, D, c["calc"], params, 7, pos, logp, 1, first + count, dtype=dtype)
+        steps = np.ascontiguousarray(ref["chain"][first:first + count])
+        cov, corr = po.reference_chain_covariance(steps, slice_interval)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, steps=steps, slice_interval=slice_interval, cov=cov, corr=corr)
+        out.append(dict(name=name, shape=list(steps.shape), slice_interval=slice_interval, bytes=os.path.getsize(path)))
+    return out
+
+
 def main():
     want = sys.argv[1:]
     if not po.reference_available():
@@ -149,6 +173,8 @@ def main():
         print(summary[-1], flush=True)
     if not want or "reference_skewed_test" in want:
         print(make_reference_test_run(), flush=True)
+    if not want or "covariance" in want:
+        print(make_covariance(), flush=True)
     if not want:
         with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
             json.dump(summary, f, indent=1)
