@@ -126,7 +126,7 @@ int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, voi
 /* Current walker state (what Walker::getCurrState / getCurrAuxData / getAcceptedProposals expose,
  * Walker/Walker.h:111-122).  n_accept[w] counts accepted proposals since set_state or reset_counters;
  * the reference additionally counts the initial placement (Walker.h:76,168) -- the facade adds it.
- * Any pointer may be NULL. */
+ * Counts stay below 2^31 (the reference's counters are 32-bit ints as well).  Any pointer may be NULL. */
 int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept);
 
 /* Checkpoint / resume.  The random stream has no per-walker state: (seed, stream, ensemble steps done) address
