@@ -386,7 +386,7 @@ public:
             HIP_TRY(hipMemcpy(d_task_jump, tj.data(), sizeof(Affine128) * tj.size(), hipMemcpyHostToDevice));
         }
 
-        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 64) : c.graph_steps;
+        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 128) : c.graph_steps;
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
         if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;
