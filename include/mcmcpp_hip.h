@@ -191,6 +191,9 @@ int mcmcpp_hip_moments_create(int32_t dtype, int32_t device, int32_t num_walkers
 void mcmcpp_hip_moments_destroy(mcmcpp_hip_moments* m);
 int mcmcpp_hip_moments_reset(mcmcpp_hip_moments* m);
 int mcmcpp_hip_moments_add_steps(mcmcpp_hip_moments* m, const void* steps, int64_t n_steps, int64_t step_stride);
+/* the same for n_steps contiguous stored steps that already live in device memory (e.g. a device chain bound with
+ * mcmcpp_hip_bind_device_chain): no upload; returns when the sums are updated */
+int mcmcpp_hip_moments_add_device_steps(mcmcpp_hip_moments* m, const void* device_steps, int64_t n_steps);
 int mcmcpp_hip_moments_finish(mcmcpp_hip_moments* m, int64_t* num_points, void* mean, void* cov, void* corr);
 const char* mcmcpp_hip_moments_last_error(const mcmcpp_hip_moments* m);
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
     "mcmcpp_hip_moments_create", "mcmcpp_hip_moments_destroy", "mcmcpp_hip_moments_reset", "mcmcpp_hip_moments_add_steps",
-    "mcmcpp_hip_moments_finish", "mcmcpp_hip_moments_last_error",
+    "mcmcpp_hip_moments_add_device_steps", "mcmcpp_hip_moments_finish", "mcmcpp_hip_moments_last_error",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
         L.mcmcpp_hip_moments_destroy.restype = None
         L.mcmcpp_hip_moments_reset.argtypes = [vp]
         L.mcmcpp_hip_moments_add_steps.argtypes = [vp, vp, i64, i64]
+        L.mcmcpp_hip_moments_add_device_steps.argtypes = [vp, vp, i64]
         L.mcmcpp_hip_moments_finish.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
         L.mcmcpp_hip_moments_last_error.argtypes = [vp]
         L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
@@ -220,6 +221,10 @@ class HipMoments:
         assert steps.ndim == 3 and steps.shape[1:] == (self.W, self.D)
         used = (steps.shape[0] + slice_interval - 1) // slice_interval
         self._check(lib().mcmcpp_hip_moments_add_steps(self.h, _ptr(steps), used, slice_interval))
+
+    def add_device_steps(self, device_ptr, n_steps):
+        """n_steps contiguous stored steps in device memory (an integer address, e.g. torch.Tensor.data_ptr())."""
+        self._check(lib().mcmcpp_hip_moments_add_device_steps(self.h, C.c_void_p(device_ptr), n_steps))
 
     def finish(self):
         t = np_dtype(self.dtype)

@@ -52,21 +52,32 @@ moments_mfma_kernel(const T* samples, long long n_samples, int dims, double* par
     double sum[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) sum[t] = 0.0;
-    for (long long g = wave; g < groups; g += waves)
+    // four groups per round: their loads are in flight together (a wavefront's chain of loads is what bounds this kernel)
+    constexpr int U = 4;
+    for (long long g0 = wave; g0 < groups; g0 += (long long)waves * U)
     {
-        const long long s = 4 * g + krow;
-        double x[TILES];
+        double x[U][TILES];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t)
+        for (int u = 0; u < U; ++u)
         {
-            const int p = 16 * t + col;
-            x[t] = (s < n_samples && p < dims) ? (double)samples[(size_t)s * dims + p] : 0.0;
-            sum[t] += x[t];
+            const long long s = 4 * (g0 + (long long)u * waves) + krow;  // (beyond the last group: s >= n_samples, zeros)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t)
+            {
+                const int p = 16 * t + col;
+                x[u][t] = (s < n_samples && p < dims) ? (double)samples[(size_t)s * dims + p] : 0.0;
+            }
         }
 #pragma unroll
-        for (int a = 0; a < TILES; ++a)
+        for (int u = 0; u < U; ++u)
+        {
 #pragma unroll
-            for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[a], x[b], acc[a][b], 0, 0, 0);
+            for (int t = 0; t < TILES; ++t) sum[t] += x[u][t];
+#pragma unroll
+            for (int a = 0; a < TILES; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(x[u][a], x[u][b], acc[a][b], 0, 0, 0);
+        }
     }
     double* slot = partial + (size_t)wave * (size_t)(DP * DP + DP);
     // C/D layout: lane l, register r -> [m = 4r + l/16][n = l%16]
@@ -226,7 +237,7 @@ int mcmcpp_hip_moments_create(int32_t dtype, int32_t device, int32_t num_walkers
     m->dp = m->matrix_core ? 16 * ((num_params + 15) / 16) : num_params;
     // slots: one per wavefront (matrix cores: 4 wavefronts per CU) / one per workgroup, bounded by 256 MiB of partials
     m->slot_elems = (size_t)m->dp * m->dp + m->dp;
-    m->slots = m->matrix_core ? prop.multiProcessorCount * kMomentWavesPerBlock : prop.multiProcessorCount;
+    m->slots = m->matrix_core ? prop.multiProcessorCount * kMomentWavesPerBlock * 2 : prop.multiProcessorCount;  // two workgroups per CU
     while (m->slots > kMomentWavesPerBlock && (size_t)m->slots * m->slot_elems * sizeof(double) > ((size_t)256 << 20)) m->slots /= 2;
     m->slots -= m->slots % kMomentWavesPerBlock;
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -302,6 +313,21 @@ int mcmcpp_hip_moments_add_steps(mcmcpp_hip_moments* m, const void* steps, int64
         if (rc) return rc;
         m->points += n_samples;
     }
+    MOM_TRY(hipStreamSynchronize(m->stream));
+    return MCMCPP_HIP_OK;
+}
+
+int mcmcpp_hip_moments_add_device_steps(mcmcpp_hip_moments* m, const void* device_steps, int64_t n_steps)
+{
+    if (!m) return MCMCPP_HIP_E_ARG;
+    if (n_steps < 0 || (n_steps > 0 && !device_steps)) return fail(m, MCMCPP_HIP_E_ARG, "moments_add_device_steps: bad arguments");
+    if (n_steps == 0) return MCMCPP_HIP_OK;
+    MOM_TRY(hipSetDevice(m->device));
+    const long long n_samples = (long long)n_steps * m->W;
+    const int rc = m->dtype == MCMCPP_HIP_F64 ? accumulate<double>(m, (const double*)device_steps, n_samples)
+                                              : accumulate<float>(m, (const float*)device_steps, n_samples);
+    if (rc) return rc;
+    m->points += n_samples;
     MOM_TRY(hipStreamSynchronize(m->stream));
     return MCMCPP_HIP_OK;
 }

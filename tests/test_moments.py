@@ -101,6 +101,19 @@ def test_device_covariance_accumulates_over_calls_and_resets():
 
 
 @pytest.mark.gpu
+def test_device_resident_steps_give_the_same_sums():
+    import torch
+    rng = np.random.default_rng(9)
+    steps = rng.standard_normal((6, 1024, 32)) + 0.5
+    a, b = capi.HipMoments(1024, 32), capi.HipMoments(1024, 32)
+    a.add_steps(steps)
+    t = torch.from_numpy(steps).cuda()
+    b.add_device_steps(t.data_ptr(), steps.shape[0])
+    for x, y in zip(a.finish(), b.finish()):
+        np.testing.assert_array_equal(x, y)                               # same kernel, same order: bit-identical
+
+
+@pytest.mark.gpu
 def test_covariance_facade_against_the_oracle():
     """include/MCMCpp/Analysis/CovarianceMatrix.h on a chain sampled through the facade (tests/cpp/covariance_facade.cpp)."""
     from tests.test_facade import BUILD, INC, LINK
