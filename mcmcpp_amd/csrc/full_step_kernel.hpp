@@ -150,8 +150,16 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const DrawRec<T> rec_r = dr_red[ir];
     const DrawRec<T> rec_b = dr_blk[ir];
     T own_r[EPL], own_b[EPL];
-    load_slice<T, EPL>(pin + (size_t)ir * h_dims, i0, h_dims, vec_ok, active, own_r);
-    load_slice<T, EPL>(pin + (size_t)(h_n + ir) * h_dims, i0, h_dims, vec_ok, active, own_b);
+    if (vec_ok)  // (one branch around both rows: see load_slice)
+    {
+        load_slice_as<T, EPL, true>(pin + (size_t)ir * h_dims, i0, h_dims, active, own_r);
+        load_slice_as<T, EPL, true>(pin + (size_t)(h_n + ir) * h_dims, i0, h_dims, active, own_b);
+    }
+    else
+    {
+        load_slice_as<T, EPL, false>(pin + (size_t)ir * h_dims, i0, h_dims, active, own_r);
+        load_slice_as<T, EPL, false>(pin + (size_t)(h_n + ir) * h_dims, i0, h_dims, active, own_b);
+    }
     const T lp_r = lin[ir];
     const T lp_b = lin[h_n + ir];
     uint32_t nacc_r = h_n_accept[ir];
@@ -163,12 +171,21 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
 
     // ---- second round trip: everything the two records point to ----
     T par_r[EPL], own_x[EPL], par_x[EPL];
-    load_slice<T, EPL>(pin + (size_t)(h_n + (int)rec_r.partner) * h_dims, i0, h_dims, vec_ok, active, par_r);
     const int jx = (int)rec_b.partner;
     const DrawRec<T> rec_x = dr_red[jx];
-    load_slice<T, EPL>(pin + (size_t)jx * h_dims, i0, h_dims, vec_ok, active, own_x);
     const T lp_x = lin[jx];
-    load_slice<T, EPL>(pin + (size_t)(h_n + (int)rec_b.partner2) * h_dims, i0, h_dims, vec_ok, active, par_x);
+    if (vec_ok)  // (one branch around the three rows: see load_slice)
+    {
+        load_slice_as<T, EPL, true>(pin + (size_t)(h_n + (int)rec_r.partner) * h_dims, i0, h_dims, active, par_r);
+        load_slice_as<T, EPL, true>(pin + (size_t)jx * h_dims, i0, h_dims, active, own_x);
+        load_slice_as<T, EPL, true>(pin + (size_t)(h_n + (int)rec_b.partner2) * h_dims, i0, h_dims, active, par_x);
+    }
+    else
+    {
+        load_slice_as<T, EPL, false>(pin + (size_t)(h_n + (int)rec_r.partner) * h_dims, i0, h_dims, active, par_r);
+        load_slice_as<T, EPL, false>(pin + (size_t)jx * h_dims, i0, h_dims, active, own_x);
+        load_slice_as<T, EPL, false>(pin + (size_t)(h_n + (int)rec_b.partner2) * h_dims, i0, h_dims, active, par_x);
+    }
     MCMCPP_STAMP(1);  // first round trip landed, second issued
     warm_launch_args<T>();  // (its wait overlaps the second round trip)
 

@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "calculators.hpp"
 #include "fast_log.hpp"
 #include "pcg128.hpp"
@@ -134,34 +136,51 @@ struct alignas(64) HalfStepArgs
     int pos_parity;             // full-step kernels: 0: read pos/logp, write pos_alt/logp_alt; 1: the reverse
 };
 
-template <class T, int EPL>
-__device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec_ok, bool active, T (&out)[EPL])
+// This lane's EPL elements of a walker row; cells beyond D (and everything when !active) are +0.  Branch-free on
+// purpose: the address is clamped to a valid one, the load is unconditional and unwanted data is masked off bitwise.
+// A load inside a branch is waited for inside that branch, which serialises what should be one round trip of many
+// loads in flight (measured in the full-step kernel: five dependent round trips instead of two).  `row` must be a
+// valid row address also for inactive lanes (callers clamp the walker index).
+template <class T, int EPL, bool VEC>
+__device__ __forceinline__ void load_slice_as(const T* row, int i0, int D, bool active, T (&out)[EPL])
 {
     constexpr int VN = Vec16<T>::N;
-    typedef typename Vec16<T>::type V;
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) out[e] = (T)0;
-    if (!active) return;
-    if (vec_ok)
+    typedef T VX __attribute__((ext_vector_type(VN)));
+    typedef typename std::conditional<sizeof(T) == 8, unsigned long long, unsigned>::type Bits;
+    if (VEC)
     {
 #pragma unroll
         for (int v = 0; v < EPL / VN; ++v)
         {
-            if (i0 + v * VN < D)
-            {
-                const V x = *reinterpret_cast<const V*>(row + i0 + v * VN);
-                const T* xs = reinterpret_cast<const T*>(&x);
+            const int col = i0 + v * VN;
+            const bool in = active && col < D;  // (D is a multiple of VN here: a piece lies wholly inside or outside)
+            const VX x = *reinterpret_cast<const VX*>(row + (in ? col : 0));
+            const Bits mask = in ? ~(Bits)0 : (Bits)0;
 #pragma unroll
-                for (int k = 0; k < VN; ++k) out[v * VN + k] = xs[k];
-            }
+            for (int k = 0; k < VN; ++k) out[v * VN + k] = __builtin_bit_cast(T, (Bits)(__builtin_bit_cast(Bits, (T)x[k]) & mask));
         }
     }
     else
     {
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
-            if (i0 + e < D) out[e] = row[i0 + e];
+        {
+            const bool in = active && i0 + e < D;
+            const T x = row[in ? i0 + e : 0];
+            const Bits mask = in ? ~(Bits)0 : (Bits)0;
+            out[e] = __builtin_bit_cast(T, (Bits)(__builtin_bit_cast(Bits, x) & mask));
+        }
     }
+}
+template <class T, int EPL>
+__device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec_ok, bool active, T (&out)[EPL])
+{
+    // (a caller with several rows to fetch in one round trip branches on vec_ok itself, around all of them: every
+    //  branch ends with a wait for the loads issued inside it)
+    if (vec_ok)
+        load_slice_as<T, EPL, true>(row, i0, D, active, out);
+    else
+        load_slice_as<T, EPL, false>(row, i0, D, active, out);
 }
 
 // Write-through stores (sc0 sc1: system scope).  What a launch writes with plain stores sits dirty in L2 until the
@@ -413,7 +432,7 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
                                                int group_walkers, int lane, bool black_only = false)
 {
 #ifdef MCMCPP_STAMPS
-    unsigned long long dstamp[5] = {0, 0, 0, 0, 0};
+    unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MCMCPP_DSTAMP(k, drain)                                                                             \
     do                                                                                                      \
     {                                                                                                       \
@@ -473,9 +492,12 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
         j_a[r] = *(direct ? a.task_jump + 3 * (size_t)jj : a.jump_hi + (jj >> 8));  // branch-free: one pointer, one load
         j_b[r] = a.jump_lo[direct ? 0u : (jj & 255u)];
     }
+    MCMCPP_DSTAMP(5, false);  // raw outputs computed, gathers issued
 #pragma unroll
     for (int r = 0; r < MAXR; ++r)
         if (ok[r]) draw_store<T>(a, kk[r], raw[r], (cc[r] ? write1 : write0) + wi[r]);
+    MCMCPP_DSTAMP(6, false);  // record fields computed and stored
+    MCMCPP_DSTAMP(7, true);   // gathers landed
 #pragma unroll
     for (int r = 0; r < MAXR; ++r)
         if (p2[r]) ((cc[r] ? write1 : write0) + wi[r])->partner2 = draw_partner2<T>(a, ctl.state2, j_a[r], j_b[r], direct);
@@ -487,7 +509,7 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
         if (blockIdx.x == 0)
         {
             dstamp[4] = __builtin_amdgcn_s_memrealtime();
-            for (int k = 0; k < 5; ++k) a.stamps[8 + 2 * 3 * 4096 + k] = dstamp[k];
+            for (int k = 0; k < 8; ++k) a.stamps[8 + 2 * 3 * 4096 + k] = dstamp[k];
         }
         a.stamps[8 + (a.pos_parity | a.color) * 3 * 4096 + 2 * 4096 + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     }

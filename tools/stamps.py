@@ -26,7 +26,7 @@ for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
         t = np.array(list(out)[:6], dtype=np.float64)
         acc.append(np.append(np.diff(t), [(out[5] - out[0]) / max(1, (out[7] - out[6])) * 100.0]))
     raw = np.array(list(out)[8:8 + 6 * 4096], dtype=np.int64).reshape(2, 3 * 4096)
-    dst = np.array(list(out)[8 + 6 * 4096:8 + 6 * 4096 + 5], dtype=np.int64)
+    dst = np.array(list(out)[8 + 6 * 4096:8 + 6 * 4096 + 8], dtype=np.int64)
     sets = []
     for k in range(2):
         bk = raw[k, :8192].reshape(-1, 2)
@@ -45,7 +45,7 @@ for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
             pend = max(prev[0][:, 1].max(), prev[1].max())
             print("   gap: previous launch's last end -> this launch's first start %d ns; previous first start -> this first start %d ns" % ((t0 - pend) * 10, (t0 - prev[0][:, 0].min()) * 10))
         if dst[0] > 0:
-            print("   draw wavefront of workgroup 0 (ns after the first start): entry %d, jump entries landed %d, past the barrier %d, draws computed %d, stores acknowledged %d" % tuple((dst - t0) * 10))
+            print("   draw wavefront of workgroup 0 (ns after the first start): entry %d, jump entries landed %d, past the barrier %d, raw outputs %d, records stored %d, gathers landed %d, partner2 done %d, stores acknowledged %d" % tuple((dst[[0, 1, 2, 5, 6, 7, 3, 4]] - t0) * 10))
         if dw.max() > 0:
             print("   draw wavefronts end: %s" % q((dw[dw > 0] - t0) * 10))
         if len(blk) >= 8: print("   by XCD (blockIdx %% 8): start p50 %s | end max %s" % ([int(np.percentile(st[k::8], 50)) for k in range(8)], [int(en[k::8].max()) for k in range(8)]))
