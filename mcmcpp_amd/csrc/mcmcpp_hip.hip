@@ -276,7 +276,7 @@ public:
         // launch is bounded by its launch boundary and latencies rather than by HBM; needs the whole ensemble here.
         full_fn = nullptr;
         if (shard_count == n && shard_begin == 0 && env_long("MCMCPP_HIP_FULL_STEP", 1) != 0 &&
-            W <= env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 24576))
+            W <= env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 32768))
         {
             full_fn = table->full_step[lpw_log][epl_shift];
             full_wpb = kWavesPerBlock * (64 / lpw);
