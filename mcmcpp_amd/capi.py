@@ -83,15 +83,16 @@ def lib():
         L.mcmcpp_hip_device_positions.restype = vp
         L.mcmcpp_hip_shard_span.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i64)]
         L.mcmcpp_hip_synchronize.argtypes = [vp]
-        L.mcmcpp_hip_moments_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
-        L.mcmcpp_hip_moments_destroy.argtypes = [vp]
-        L.mcmcpp_hip_moments_destroy.restype = None
-        L.mcmcpp_hip_moments_reset.argtypes = [vp]
-        L.mcmcpp_hip_moments_add_steps.argtypes = [vp, vp, i64, i64]
-        L.mcmcpp_hip_moments_add_device_steps.argtypes = [vp, vp, i64]
-        L.mcmcpp_hip_moments_finish.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
-        L.mcmcpp_hip_moments_last_error.argtypes = [vp]
-        L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
+        if hasattr(L, "mcmcpp_hip_moments_create"):  # (absent only from older experiment builds selected with MCMCPP_HIP_LIB)
+            L.mcmcpp_hip_moments_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+            L.mcmcpp_hip_moments_destroy.argtypes = [vp]
+            L.mcmcpp_hip_moments_destroy.restype = None
+            L.mcmcpp_hip_moments_reset.argtypes = [vp]
+            L.mcmcpp_hip_moments_add_steps.argtypes = [vp, vp, i64, i64]
+            L.mcmcpp_hip_moments_add_device_steps.argtypes = [vp, vp, i64]
+            L.mcmcpp_hip_moments_finish.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
+            L.mcmcpp_hip_moments_last_error.argtypes = [vp]
+            L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 

@@ -14,8 +14,12 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave);
-    hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? 1 : 0))), lds, st, a.draws,
-                       a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+    if (a.draw_wave)
+        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos, a.logp,
+                           a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+    else
+        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos, a.logp,
+                           a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW, int P>
@@ -23,8 +27,12 @@ void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave);
-    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? 1 : 0))), lds, st,
-                       a.draws, a.pos, a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+    if (a.draw_wave)
+        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos,
+                           a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+    else
+        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, false>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos,
+                           a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>

@@ -249,7 +249,10 @@ public:
                         prop.gcnArchName);
         num_cus = prop.multiProcessorCount;
 
-        // walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then amortise the per-walker draw computation
+        // Walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then up to 8 per wavefront (still
+        // served by the draw wavefront) and 16 for the largest ensembles.  Measured, 32 dims fp64 (tools/sweep_passes.txt):
+        // 65 536 walkers 5.2 / 5.8 / 4.4e9 walker-steps/s with 4 / 8 / 16 walkers per wavefront, 262 144: 7.4e9 with 8,
+        // 1 M: 6.7 / 8.0 / 7.8 / 7.4e9 with 8 / 16 / 32 / 64.
         const int wpp = 64 / lpw;
         long forced = env_long("MCMCPP_HIP_PASSES", 0);
         if (forced > 0)
@@ -257,8 +260,9 @@ public:
         else
         {
             const long target_waves = (long)num_cus * 4 * env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
+            const int per_wave_cap = shard_count > 196608 ? 16 : 8;
             passes = 1;
-            while (passes * 2 <= lpw && (long)shard_count / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
+            while (passes * 2 <= lpw && wpp * passes * 2 <= per_wave_cap && (long)shard_count / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
         }
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;

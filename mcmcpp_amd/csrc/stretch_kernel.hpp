@@ -538,8 +538,12 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
 #endif
 }
 
-template <class T, class Calc, int EPL, int LPW>
-__global__ void __launch_bounds__(64 * (kWavesPerBlock + 1))
+// DW: built with the extra draw wavefront (HalfStepArgs::draw_wave) or without it.  Two instantiations on purpose: the
+// draw wavefront's code raises the kernel's register count (85 against 64 VGPRs for the isotropic target), which
+// costs the variant without it -- the one large, bandwidth-bound ensembles take -- occupancy (measured at 1 M
+// walkers: 73.7 against 68.8 us per launch).
+template <class T, class Calc, int EPL, int LPW, bool DW>
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                          int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
@@ -548,7 +552,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     const HalfStepArgs<T>& a = rest;
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
-    const bool h_draw_wave = ((hot_bits >> 25) & 1u) != 0;
+    constexpr bool h_draw_wave = DW;  // (hot_bits bit 25 says the same)
     // draw records: this launch reads buffer `parity`, the draws of the colour's next update go to the other one
     const DrawRec<T>* const h_draws = hot_draws + ((size_t)h_parity * 2 + (size_t)h_color) * (size_t)hot_n;
     DrawRec<T>* const h_draws_next = hot_draws + ((size_t)(1 - h_parity) * 2 + (size_t)h_color) * (size_t)hot_n;
@@ -582,12 +586,15 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int nw = WPP * h_passes;
-    if (wib == kWavesPerBlock)
+    if constexpr (DW)
     {
-        // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-        draw_wave_body<T, 2>(a, hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0, h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count,
-                             blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
-        return;
+        if (wib == kWavesPerBlock)
+        {
+            // the workgroup's extra wavefront: next draws of every walker this workgroup updates
+            draw_wave_body<T, 2>(a, hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0, h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count,
+                                 blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
+            return;
+        }
     }
     const int wave = blockIdx.x * kWavesPerBlock + wib;
     const int first = wave * nw;  // first walker of this wavefront, relative to the shard
@@ -697,10 +704,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
             }
         }
     };
-    // (the record buffers alternate, so the order against the update loop no longer matters for correctness;
-    //  in the shadow of the gather is where the arithmetic costs least)
-    if (!h_draw_wave) next_draws();
-    MCMCPP_STAMP(2);  // next draws done
+    MCMCPP_STAMP(2);
 
     // ---------------- the update: LPW lanes per walker ------------------------------------------------------
     unsigned accepted_here = 0;
@@ -779,6 +783,11 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         nacc_old = nacc_next;
         rec = rec_next;
     }
+    // Without a draw wavefront (many walkers per wavefront: large, bandwidth-bound ensembles, or very few
+    // dimensions) the next draws are made here, when the update loop's registers are free: made in the shadow of the
+    // gather they lift the kernel from 64 to 85 VGPRs and cost occupancy (7 % at 1 M walkers).  The record buffers
+    // alternate, so the order against the update loop is free as far as correctness goes.
+    if (!h_draw_wave) next_draws();
     MCMCPP_STAMP(5);  // all stores of this wavefront acknowledged
 #ifdef MCMCPP_STAMPS
     if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
@@ -880,8 +889,8 @@ __device__ __forceinline__ void mc_eval(const McB& B, double* sx, int sub, int g
 }
 
 // P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
-template <class T, class Calc, int EPL, int LPW, int P>
-__global__ void __launch_bounds__(64 * (kWavesPerBlock + 1))
+template <class T, class Calc, int EPL, int LPW, int P, bool DW>
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
@@ -903,7 +912,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     MCMCPP_STAMP_BLOCK(0);
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
-    const bool h_draw_wave = ((hot_bits >> 25) & 1u) != 0;
+    constexpr bool h_draw_wave = DW;
     const DrawRec<T>* const h_draws = hot_draws + ((size_t)h_parity * 2 + (size_t)h_color) * (size_t)hot_n;
     DrawRec<T>* const h_draws_next = hot_draws + ((size_t)(1 - h_parity) * 2 + (size_t)h_color) * (size_t)hot_n;
     T* const h_pos = hot_pos;
@@ -916,12 +925,15 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     const int h_shard_count = hot_shard_count;
 
     const int lane = threadIdx.x & 63;
-    if ((threadIdx.x >> 6) == kWavesPerBlock)
+    if constexpr (DW)
     {
-        // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-        draw_wave_body<T, 2>(a, hot_ctl_in, true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
-                             h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane);
-        return;
+        if ((threadIdx.x >> 6) == kWavesPerBlock)
+        {
+            // the workgroup's extra wavefront: next draws of every walker this workgroup updates
+            draw_wave_body<T, 2>(a, hot_ctl_in, true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
+                                 h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane);
+            return;
+        }
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int first = wave * NW;
