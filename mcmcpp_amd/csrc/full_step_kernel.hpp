@@ -32,7 +32,10 @@ namespace mcmcpp
 {
 
 constexpr uint32_t kRowMovedBit = 0x80000000u;  // in n_accept[w]: the walker's row in the other position buffer is out of date
-constexpr int kFullDrawWaves = 4;  // extra wavefronts of a full-step workgroup: next red draws (2), next black draws (2)
+#ifndef MCMCPP_FULL_DRAW_WAVES
+#define MCMCPP_FULL_DRAW_WAVES 4
+#endif
+constexpr int kFullDrawWaves = MCMCPP_FULL_DRAW_WAVES;  // extra wavefronts of a full-step workgroup: 4 = next red draws (2), next black draws (2); 2 = one per colour
 
 // Hands the random stream and the step counters to the next full-step launch (one lane of the whole grid).
 template <class T>
@@ -81,8 +84,8 @@ template <class T>
 __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const StepCtl* ctl_ptr, bool block_barrier, DrawRec<T>* dn_red, int n,
                                                     int wpb, int which, int lane)
 {
-    const int black = which >> 1, half = which & 1;
-    const int h0 = (wpb + 1) / 2;  // walkers of the first half
+    const int black = kFullDrawWaves == 4 ? which >> 1 : which, half = kFullDrawWaves == 4 ? (which & 1) : 0;
+    const int h0 = kFullDrawWaves == 4 ? (wpb + 1) / 2 : wpb;  // walkers of the first half
     if (which == 0) trickle_stored_step(*a.run, *ctl_ptr, lane);
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
     draw_wave_body<T, 1>(a, ctl_ptr, block_barrier, dst, dst, 1, 0, n, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0);

@@ -960,7 +960,7 @@ private:
             a.ctl_out = d_ctl + (1 - pos_parity);
             a.partial_waves = partial_waves;
             // the next draws by four extra wavefronts (two per colour) when that is one round of 64 draws each
-            a.draw_wave = (3 * ((full_wpb + 1) / 2) <= 64 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
+            a.draw_wave = (3 * (kFullDrawWaves == 4 ? (full_wpb + 1) / 2 : full_wpb) <= 64 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
             full_fn(a, full_grid_blocks(), stream);
             return;
         }

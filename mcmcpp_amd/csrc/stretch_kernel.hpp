@@ -261,7 +261,10 @@ __device__ __forceinline__ float dev_log(float x) { return logf(x); }
 __device__ __forceinline__ double dev_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float dev_abs(float x) { return fabsf(x); }
 
-constexpr int kWavesPerBlock = 4;
+#ifndef MCMCPP_WAVES_PER_BLOCK  // (experiment builds: make VARIANT=... EXTRA=-DMCMCPP_WAVES_PER_BLOCK=2)
+#define MCMCPP_WAVES_PER_BLOCK 4
+#endif
+constexpr int kWavesPerBlock = MCMCPP_WAVES_PER_BLOCK;
 
 // Diagnostic build only (make STAMPS=1 -> libmcmcpp_hip_stamps.so): wavefront 0 of workgroup 0 drains its
 // memory counters and records the shader clock at a few points; the product build compiles none of it.
