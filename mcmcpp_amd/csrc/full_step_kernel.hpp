@@ -50,7 +50,7 @@ __device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const S
     nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
     nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
     nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
-    *a.ctl_out = nx;
+    *a.ctl_out = nx;  // (plain stores: written through, this and the partial counts below cost 0.2 us per launch)
 }
 
 // hot_bits of the full-step kernels: HotBits::pack(...) | pos_parity << 26
