@@ -56,44 +56,24 @@ __device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const S
 // hot_bits of the full-step kernels: HotBits::pack(...) | pos_parity << 26
 __host__ __device__ inline uint32_t full_step_bits(uint32_t half_bits, int pos_parity) { return half_bits | ((uint32_t)pos_parity << 26); }
 
-// Stored steps reach the host without a copy engine and without a gap in the launch sequence: every launch forwards
-// 1/interval of the most recent stored step from the device chain ring to its twin in pinned host memory (one
-// 16-byte piece per lane, spread over the first draw wavefront of every workgroup, written through so that the
-// PCIe traffic leaves while the kernel is still busy; measured: up to ~64 KB per launch are free, a separate copy
-// of the 4 MiB step costs 75 us of the launch stream).  Stored step k is complete in host memory when ensemble step
-// (k + 2) * interval - 1 has finished; the host copies the run's last stored step itself.
-__device__ __forceinline__ void trickle_stored_step(const RunInfo& run, const StepCtl& ctl, int lane)
-{
-    const long long prev = run.chain_slot_base + ctl.chain_slot - 1;  // the stored step before the one this interval ends with
-    if (run.stage == nullptr || prev < 0) return;
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const size_t slot_off = (size_t)(prev & run.slot_mask) * (size_t)run.step_bytes;
-    const size_t begin = (size_t)ctl.save_phase * (size_t)run.slice_bytes;
-    size_t end = begin + (size_t)run.slice_bytes;
-    if (end > (size_t)run.step_bytes) end = (size_t)run.step_bytes;
-    const char* src = static_cast<const char*>(run.chain) + slot_off;
-    char* dst = static_cast<char*>(run.stage) + slot_off;
-    for (size_t off = begin + ((size_t)blockIdx.x * 64 + (size_t)lane) * 16; off < end; off += (size_t)gridDim.x * 64 * 16)
-        store_through16(dst + off, *reinterpret_cast<const v4u*>(src + off));
-}
-
 // the workgroup's extra wavefronts: the draws of the NEXT ensemble step of every walker this workgroup updates
 // (`wpb` of each colour, starting at walker blockIdx.x * wpb); extra wavefronts 0, 1 make the red records of the first
 // and second half of those walkers, 2 and 3 the black ones
 template <class T>
-__device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const StepCtl* ctl_ptr, bool block_barrier, DrawRec<T>* dn_red, int n,
-                                                    int wpb, int which, int lane)
+__device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, const RunInfo* run_ptr,
+                                                    bool block_barrier, DrawRec<T>* dn_red, int n, int wpb, int which, int lane)
 {
     const int black = kFullDrawWaves == 4 ? which >> 1 : which, half = kFullDrawWaves == 4 ? (which & 1) : 0;
     const int h0 = kFullDrawWaves == 4 ? (wpb + 1) / 2 : wpb;  // walkers of the first half
-    if (which == 0) trickle_stored_step(*a.run, *ctl_ptr, lane);
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
-    draw_wave_body<T, 1>(a, ctl_ptr, block_barrier, dst, dst, 1, 0, n, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0);
+    // (the first of them also forwards this launch's slice of the last stored step: trickle_stored_step)
+    draw_wave_body<T, 1>(a, tab, ctl_ptr, block_barrier, dst, dst, 1, 0, n, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0,
+                         which == 0 ? run_ptr : nullptr);
 }
 
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
-stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, T* hot_logp_b, uint32_t* hot_n_accept, int hot_n,
+stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const RunInfo* hot_run, uint32_t* hot_n_accept, int hot_n,
                          uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     const HalfStepArgs<T>& a = rest;
@@ -111,6 +91,7 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     DrawRec<T>* const dn_blk = dn_red + h_n;
     const T* const pin = h_flip ? hot_pos_b : hot_pos_a;
     T* const pout = h_flip ? hot_pos_a : hot_pos_b;
+    T* const hot_logp_b = hot_logp_a + 2 * (size_t)h_n;  // (the two log-posterior buffers are one allocation: [2][W])
     const T* const lin = h_flip ? hot_logp_b : hot_logp_a;
     T* const lout = h_flip ? hot_logp_a : hot_logp_b;
     uint32_t* const h_n_accept = hot_n_accept;
@@ -129,7 +110,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const int wib = threadIdx.x >> 6;
     if (wib >= kWavesPerBlock)
     {
-        full_step_draw_wave<T>(a, hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0, dn_red, h_n, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane);
+        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, Calc::block_scratch_elems(h_dims) != 0,
+                               dn_red, h_n, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -167,10 +149,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const T lp_b = lin[h_n + ir];
     uint32_t nacc_r = h_n_accept[ir];
     uint32_t nacc_b = h_n_accept[h_n + ir];
-    const StepCtl ctl = *hot_ctl_in;  // wave-uniform
     typename Calc::Prefetch calc_pf;
     Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
-    const RunInfo run = *a.run;
 
     // ---- second round trip: everything the two records point to ----
     T par_r[EPL], own_x[EPL], par_x[EPL];
@@ -190,7 +170,12 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
         load_slice_as<T, EPL, false>(pin + (size_t)(h_n + (int)rec_b.partner2) * h_dims, i0, h_dims, active, par_x);
     }
     MCMCPP_STAMP(1);  // first round trip landed, second issued
-    warm_launch_args<T>();  // (its wait overlaps the second round trip)
+    // Every scalar miss of this wavefront is taken here, in one batch whose wait overlaps the second round trip: the
+    // control and run records (preloaded pointers) and all lines of the launch description (cold misses of the order of
+    // a microsecond each; issued one by one where first needed they delayed the calculator by about that much).
+    StepCtl ctl;  // wave-uniform
+    RunInfo run;
+    load_records_and_warm_args<T>(hot_ctl_in, hot_run, ctl, run);
 
     // ---- in its shadow: the calculator's tables, the hand-over to the next launch ----
     const bool has_block_scratch = Calc::block_scratch_elems(h_dims) != 0;
@@ -335,7 +320,7 @@ __device__ __forceinline__ void store_row_piece(double* p, double x0, double x1)
 
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
-stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, T* hot_logp_b, uint32_t* hot_n_accept, int hot_n,
+stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, const RunInfo* hot_run, int hot_n,
                               uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
@@ -361,14 +346,17 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     DrawRec<T>* const dn_red = hot_draws + (size_t)(1 - h_parity) * 2 * (size_t)h_n;
     const T* const pin = h_flip ? hot_pos_b : hot_pos_a;
     T* const pout = h_flip ? hot_pos_a : hot_pos_b;
+    T* const hot_logp_b = hot_logp_a + 2 * (size_t)h_n;  // (the two log-posterior buffers are one allocation: [2][W])
     const T* const lin = h_flip ? hot_logp_b : hot_logp_a;
     T* const lout = h_flip ? hot_logp_a : hot_logp_b;
-    uint32_t* const h_n_accept = hot_n_accept;
+    // (log-posteriors [2][W] and accepted counters [W] are one allocation: the counters' address is derived)
+    uint32_t* const h_n_accept = reinterpret_cast<uint32_t*>(hot_logp_a + 4 * (size_t)h_n);
 
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
-        full_step_draw_wave<T>(a, hot_ctl_in, false, dn_red, h_n, kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane);
+        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, false, dn_red, h_n, kWavesPerBlock * NW,
+                               (int)(threadIdx.x >> 6) - kWavesPerBlock, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -409,10 +397,9 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         nacc_r[q] = h_n_accept[ir[q]];
         nacc_b[q] = h_n_accept[h_n + ir[q]];
     }
-    const StepCtl ctl = *hot_ctl_in;
     McB matB;
-    mc_load_b(a.calc_params_padded, sub, grp, matB);  // 8 x 16 bytes per lane, the same 8 KiB for every wavefront: L2 hits
-    const RunInfo run = *a.run;
+    mc_load_b(hot_matrix, sub, grp, matB);  // 8 x 16 bytes per lane, the same 8 KiB for every wavefront: L2 hits; the pointer is
+                                            // a preloaded argument: no kernarg miss in front of these loads or of the second trip
 
     // ---- second round trip: everything the records point to ----
     T par_r[2][2], own_x[2][2], par_x[2][2], lp_x[2];
@@ -428,7 +415,10 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         load_row(pin, h_n + (int)rec_b[q].partner2, par_x[q]);
     }
     MCMCPP_STAMP(1);
-    warm_launch_args<T>();  // (its wait overlaps the second round trip)
+    // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
+    StepCtl ctl;
+    RunInfo run;
+    load_records_and_warm_args<T>(hot_ctl_in, hot_run, ctl, run);
     if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run);
     long long save_slot = -1;
     if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;

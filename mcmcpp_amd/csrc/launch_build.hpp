@@ -13,7 +13,7 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave);
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr);
     if (a.draw_wave)
         hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos, a.logp,
                            a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
@@ -26,7 +26,7 @@ template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
-    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave);
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr);
     if (a.draw_wave)
         hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos,
                            a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
@@ -39,18 +39,20 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave), a.pos_parity);
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr), a.pos_parity);
     hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
-                       st, a.draws, a.pos, a.pos_alt, a.logp, a.logp_alt, a.n_accept, a.n, bits, a.ctl_in, a);
+                       st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.n_accept, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>
 void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
-    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1), a.pos_parity);
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity);
+    // (logp_alt == logp + W and n_accept == logp + 2 W: the kernel derives them and takes the padded matrix and the
+    //  run record's address as preloaded arguments instead)
     hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
-                       a.pos, a.pos_alt, a.logp, a.logp_alt, a.n_accept, a.n, bits, a.ctl_in, a);
+                       a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.run, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>

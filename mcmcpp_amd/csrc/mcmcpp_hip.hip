@@ -316,9 +316,8 @@ public:
             const size_t graph_len = (size_t)(c.graph_steps == 0 ? env_long("MCMCPP_HIP_GRAPH_STEPS", 128) : (c.graph_steps > 0 ? c.graph_steps : 1));
             const size_t waves_bound = (size_t)n + 64;  // no kernel uses more wavefronts per colour than walkers
             size_t need = 2 * sizeof(T) * (size_t)W * D                 // pos, pos_alt
-                          + sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W + sizeof(DrawRec<T>) * (size_t)W * 2
+                          + sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W + tables_total_bytes(n, true)
                           + sizeof(T) * ((size_t)(c.calc_params_len > 0 ? c.calc_params_len : 0) + 32 * 32)
-                          + sizeof(Affine128) * ((size_t)3 * n + (size_t)(n + 255) / 256 + 256)
                           + sizeof(uint32_t) * graph_len * 2 * waves_bound + 64 * 1024;
             HIP_TRY(hipMalloc(&arena, need));
             arena_bytes = need;
@@ -335,14 +334,27 @@ public:
             if (int rc = carve(&d_pos, sizeof(T) * (size_t)W * D)) return rc;
             own_pos = true;
         }
-        if (int rc = carve(&d_logp, sizeof(T) * (size_t)W * 2)) return rc;  // [2][W]: the second half is the full-step kernels' other buffer
+        // log-posteriors [2][W] (the second half is the full-step kernels' other buffer) and, right behind them, the
+        // accepted counters [W]: one piece, so that kernels short of preloaded arguments can derive both addresses
+        if (int rc = carve(&d_logp, sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W)) return rc;
+        d_nacc = reinterpret_cast<uint32_t*>(d_logp + 2 * (size_t)W);
         if (full_fn)
             if (int rc = carve(&d_pos_alt, sizeof(T) * (size_t)W * D)) return rc;
-        if (int rc = carve(&d_nacc, sizeof(uint32_t) * (size_t)W)) return rc;
         if (int rc = carve(&d_ctl, sizeof(StepCtl) * 2)) return rc;
         if (int rc = carve(&d_run, sizeof(RunInfo))) return rc;
         if (int rc = carve(&d_diag, sizeof(Diag))) return rc;
-        if (int rc = carve(&d_draws, sizeof(DrawRec<T>) * (size_t)W * 2)) return rc;  // two buffers: see HalfStepArgs::draws
+        // the draw records (two buffers: see HalfStepArgs::draws) and, right behind them, the jump tables: one piece
+        // whose layout follows from n alone (JumpTables), so that kernels reach the tables from the record pointer
+        static_assert(sizeof(DrawRec<T>) == 32, "the table offsets assume 32-byte records");
+        have_task_table = (size_t)3 * n * sizeof(Affine128) <= ((size_t)env_long("MCMCPP_HIP_TASK_TABLE_MB", 16) << 20);
+        {
+            char* piece = nullptr;
+            if (int rc = carve(&piece, tables_total_bytes(n, have_task_table))) return rc;
+            d_draws = reinterpret_cast<DrawRec<T>*>(piece);
+            d_task_jump = have_task_table ? reinterpret_cast<Affine128*>(piece + tables_offset_task(n)) : nullptr;
+            d_jump_hi = reinterpret_cast<Affine128*>(piece + tables_offset_hi(n, have_task_table));
+            d_jump_lo = reinterpret_cast<Affine128*>(piece + tables_offset_lo(n, have_task_table));
+        }
         HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2));
 #ifdef MCMCPP_STAMPS
         HIP_TRY(hipMalloc(&d_stamps, kStampWords * sizeof(unsigned long long)));  // [8 stamps][2 alternating launches][start, end of 4096 workgroups | end of their draw wavefronts]
@@ -388,19 +400,16 @@ public:
             const Affine128 step768 = pcg_jump(inc, 768);
             hi[0] = lo[0];
             for (size_t m = 1; m < hi.size(); ++m) hi[m] = compose(step768, hi[m - 1]);
-            if (int rc = carve(&d_jump_lo, sizeof(Affine128) * lo.size())) return rc;
-            if (int rc = carve(&d_jump_hi, sizeof(Affine128) * hi.size())) return rc;
             HIP_TRY(hipMemcpy(d_jump_lo, lo.data(), sizeof(Affine128) * lo.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
         }
         half_jump = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n);
-        if ((size_t)3 * n * sizeof(Affine128) <= ((size_t)env_long("MCMCPP_HIP_TASK_TABLE_MB", 16) << 20))
+        if (have_task_table)
         {
             std::vector<Affine128> tj((size_t)3 * n);
             const Affine128 step1 = pcg_jump(inc, 1);
             tj[0] = step1;
             for (size_t t = 1; t < tj.size(); ++t) tj[t] = compose(step1, tj[t - 1]);
-            if (int rc = carve(&d_task_jump, sizeof(Affine128) * tj.size())) return rc;
             HIP_TRY(hipMemcpy(d_task_jump, tj.data(), sizeof(Affine128) * tj.size(), hipMemcpyHostToDevice));
         }
 
@@ -1166,7 +1175,8 @@ private:
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     uint32_t* d_partials = nullptr;
     int partial_slots = 1, partial_waves = 0;
-    Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_task_jump = nullptr;
+    Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_task_jump = nullptr;  // behind d_draws: see JumpTables
+    bool have_task_table = false;
     void* h_pinned = nullptr;
     U128 state0, inc;
     Affine128 half_jump;

@@ -82,6 +82,38 @@ struct Diag
     unsigned long long redraws;
 };
 
+// The jump tables live right behind the draw records, at offsets that follow from the number of walkers per colour
+// alone, so that a kernel can reach them from its preloaded record pointer without touching the kernarg segment
+// (a draw wavefront's first loads would otherwise wait for a cold scalar miss):
+//   [records: 4 n x 32 B][task_jump: 3 n entries, if built][jump_hi: ceil(n / 256) entries][jump_lo: 256 entries]
+// every piece rounded up to 256 bytes.
+struct JumpTables
+{
+    const Affine128* task;  // nullptr when the table was not built (very large ensembles)
+    const Affine128* hi;
+    const Affine128* lo;
+};
+__host__ __device__ inline size_t round_up_256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t tables_offset_task(int n) { return round_up_256((size_t)4 * (size_t)n * 32); }
+__host__ __device__ inline size_t tables_offset_hi(int n, bool direct)
+{
+    return tables_offset_task(n) + (direct ? round_up_256((size_t)3 * (size_t)n * sizeof(Affine128)) : 0);
+}
+__host__ __device__ inline size_t tables_offset_lo(int n, bool direct)
+{
+    return tables_offset_hi(n, direct) + round_up_256((size_t)((n + 255) / 256) * sizeof(Affine128));
+}
+__host__ __device__ inline size_t tables_total_bytes(int n, bool direct) { return tables_offset_lo(n, direct) + 256 * sizeof(Affine128); }
+__device__ __forceinline__ JumpTables jump_tables_behind(const void* draws_base, int n, bool direct)
+{
+    const char* b = static_cast<const char*>(draws_base);
+    JumpTables t;
+    t.task = direct ? reinterpret_cast<const Affine128*>(b + tables_offset_task(n)) : nullptr;
+    t.hi = reinterpret_cast<const Affine128*>(b + tables_offset_hi(n, direct));
+    t.lo = reinterpret_cast<const Affine128*>(b + tables_offset_lo(n, direct));
+    return t;
+}
+
 // The launch description.  It travels by value in the kernarg segment (behind 64 bytes of preloaded hot arguments)
 // and is read with scalar loads where a field is first used; after a launch boundary every 64-byte line of it is a
 // cold miss of several hundred ns, so the fields are grouped by who needs them first: a draw wavefront touches the
@@ -321,14 +353,42 @@ struct LdsLayout
 // free (behind the first vector loads of an updating wavefront; first thing in a draw wavefront).
 // (The kernels' argument lists are 64 bytes of preloaded hot arguments followed by the HalfStepArgs: the struct
 // occupies bytes 64 .. 64 + sizeof of the kernarg segment; the hidden arguments follow it.)
+// The control record, the run record and every line of the launch description in ONE batch of scalar loads with one
+// wait.  Inline assembly on purpose: as plain loads the compiler issues each where it is first needed -- three
+// dependent cold misses in a row along a wavefront's path -- and is free to hoist a wait in front of vector loads
+// that should have gone out first (it did: in front of the second round trip).
 template <class T>
-__device__ __forceinline__ void warm_launch_args()
+__device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_ptr, const RunInfo* run_ptr, StepCtl& ctl, RunInfo& run)
 {
     static_assert(64 + sizeof(HalfStepArgs<T>) > 0x180 && 64 + sizeof(HalfStepArgs<T>) <= 0x200, "adjust the lines touched below");
-    typedef const __attribute__((address_space(4))) uint32_t* KernargPtr;
-    const KernargPtr k = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    const uint32_t t1 = k[0x40 / 4], t2 = k[0x80 / 4], t3 = k[0xc0 / 4], t4 = k[0x100 / 4], t5 = k[0x140 / 4], t6 = k[0x180 / 4], t7 = k[0x1c0 / 4];
-    asm volatile("" ::"s"(t1), "s"(t2), "s"(t3), "s"(t4), "s"(t5), "s"(t6), "s"(t7));  // loaded and waited for, here
+    static_assert(sizeof(StepCtl) == 64 && sizeof(RunInfo) == 64, "one s_load_dwordx16 each");
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    const unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    // (wave-uniform by construction; made so for the compiler too: the pointers may have been chosen by wavefront index)
+    auto uniform = [](const void* p) {
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    const unsigned long long ctl_addr = uniform(ctl_ptr), run_addr = uniform(run_ptr);
+    v16u c, r;
+    unsigned t1, t2, t3, t4, t5, t6, t7;
+    asm volatile(
+        "s_load_dwordx16 %0, %9, 0x0\n\t"
+        "s_load_dwordx16 %1, %10, 0x0\n\t"
+        "s_load_dword %2, %11, 0x40\n\t"
+        "s_load_dword %3, %11, 0x80\n\t"
+        "s_load_dword %4, %11, 0xc0\n\t"
+        "s_load_dword %5, %11, 0x100\n\t"
+        "s_load_dword %6, %11, 0x140\n\t"
+        "s_load_dword %7, %11, 0x180\n\t"
+        "s_load_dword %8, %11, 0x1c0\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(c), "=&s"(r), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
+        : "s"(ctl_addr), "s"(run_addr), "s"(k)
+        : "memory");
+    ctl = __builtin_bit_cast(StepCtl, c);
+    run = __builtin_bit_cast(RunInfo, r);
 }
 
 // One random draw of one walker: task k of the walker at position i of the half (draw 3*i + k of the
@@ -416,12 +476,13 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
 // everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
 struct HotBits
 {
+    // (bit 26: full-step kernels' position-buffer parity; bit 27: the one-entry-per-draw jump table exists)
     static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save,
-                                             int draw_parity, int draw_wave)
+                                             int draw_parity, int draw_wave, int direct_jump)
     {
         return (uint32_t)dims | ((uint32_t)passes << 12) | ((uint32_t)color << 20) | ((uint32_t)vec_ok << 21) |
                ((uint32_t)n_is_pow2 << 22) | ((uint32_t)use_ctl_save << 23) | ((uint32_t)draw_parity << 24) |
-               ((uint32_t)draw_wave << 25);
+               ((uint32_t)draw_wave << 25) | ((uint32_t)direct_jump << 27);
     }
 };
 
@@ -445,6 +506,27 @@ __device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCt
     *a.ctl_out = nx;
 }
 
+// Stored steps reach the host without a copy engine and without a gap in the launch sequence: every launch forwards
+// 1/interval of the most recent stored step from the device chain ring to its twin in pinned host memory (one
+// 16-byte piece per lane, spread over the first draw wavefront of every workgroup, written through so that the
+// PCIe traffic leaves while the kernel is still busy; measured: up to ~64 KB per launch are free, a separate copy
+// of the 4 MiB step costs 75 us of the launch stream).  Stored step k is complete in host memory when ensemble step
+// (k + 2) * interval - 1 has finished; the host copies the run's last stored step itself.
+__device__ __forceinline__ void trickle_stored_step(const RunInfo& run, const StepCtl& ctl, int lane)
+{
+    const long long prev = run.chain_slot_base + ctl.chain_slot - 1;  // the stored step before the one this interval ends with
+    if (run.stage == nullptr || prev < 0) return;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const size_t slot_off = (size_t)(prev & run.slot_mask) * (size_t)run.step_bytes;
+    const size_t begin = (size_t)ctl.save_phase * (size_t)run.slice_bytes;
+    size_t end = begin + (size_t)run.slice_bytes;
+    if (end > (size_t)run.step_bytes) end = (size_t)run.step_bytes;
+    const char* src = static_cast<const char*>(run.chain) + slot_off;
+    char* dst = static_cast<char*>(run.stage) + slot_off;
+    for (size_t off = begin + ((size_t)blockIdx.x * 64 + (size_t)lane) * 16; off < end; off += (size_t)gridDim.x * 64 * 16)
+        store_through16(dst + off, *reinterpret_cast<const v4u*>(src + off));
+}
+
 // Body of the workgroup's extra wavefront (when HalfStepArgs::draw_wave): the next draws of all walkers the
 // workgroup updates -- `group_walkers` walkers of each of `colours` colours (1: a half-step launch, base state
 // ctl.state2; 2: a full-step launch, red then black, the black base one half-step further), starting at walker
@@ -452,9 +534,10 @@ __device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCt
 // critical path; its own chain is kept short by fetching every round's jump entries before anything else (and
 // before the workgroup barrier the updating wavefronts need for their tables, when there is one).
 template <class T, int MAXR>
-__device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const StepCtl* ctl_ptr, bool block_barrier, DrawRec<T>* write0,
-                                               DrawRec<T>* write1, int colours, int shard_begin, int shard_count, int group_first,
-                                               int group_walkers, int lane, bool black_only = false)
+__device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, bool block_barrier,
+                                               DrawRec<T>* write0, DrawRec<T>* write1, int colours, int shard_begin, int shard_count,
+                                               int group_first, int group_walkers, int lane, bool black_only = false,
+                                               const RunInfo* trickle_run = nullptr)
 {
 #ifdef MCMCPP_STAMPS
     unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -471,7 +554,7 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
     } while (0)
 #endif
     MCMCPP_DSTAMP(0, false);
-    const bool direct = a.task_jump != nullptr;
+    const bool direct = tab.task != nullptr;
     const int per_colour = 3 * group_walkers;
     const int tasks = colours * per_colour;
     const int last = shard_begin + shard_count - 1;
@@ -488,10 +571,17 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
         kk[r] = tt - 3 * slot;
         ok[r] = t < tasks && group_first + slot < shard_count;
         wi[r] = min(shard_begin + group_first + slot, last);  // always a valid table index: the loads are unconditional
-        j_a[r] = *(direct ? a.task_jump + (3 * wi[r] + kk[r]) : a.jump_hi + (wi[r] >> 8));  // branch-free: one pointer, one load
-        j_b[r] = a.jump_lo[direct ? 0 : (wi[r] & 255)];
+        // (table addresses from preloaded arguments: these loads go out before any scalar miss is waited for)
+        j_a[r] = *(direct ? tab.task + (3 * wi[r] + kk[r]) : tab.hi + (wi[r] >> 8));  // branch-free: one pointer, one load
+        j_b[r] = tab.lo[direct ? 0 : (wi[r] & 255)];
     }
-    const StepCtl ctl = *ctl_ptr;
+    // the control record and the lines of the launch description this wavefront needs, in one batch of scalar loads
+    StepCtl ctl;
+    {
+        RunInfo run;  // (only wanted when this wavefront also forwards stored steps; otherwise the control record twice)
+        load_records_and_warm_args<T>(ctl_ptr, trickle_run != nullptr ? trickle_run : reinterpret_cast<const RunInfo*>(ctl_ptr), ctl, run);
+        if (trickle_run != nullptr) trickle_stored_step(run, ctl, lane);
+    }
     MCMCPP_DSTAMP(1, true);
     if (block_barrier) __syncthreads();  // keep the workgroup barrier count whole
     MCMCPP_DSTAMP(2, false);
@@ -514,8 +604,8 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const S
     for (int r = 0; r < MAXR; ++r)
     {
         const uint32_t jj = p2[r] ? draw_partner<T>(a, raw[r]) : 0u;
-        j_a[r] = *(direct ? a.task_jump + 3 * (size_t)jj : a.jump_hi + (jj >> 8));  // branch-free: one pointer, one load
-        j_b[r] = a.jump_lo[direct ? 0u : (jj & 255u)];
+        j_a[r] = *(direct ? tab.task + 3 * (size_t)jj : tab.hi + (jj >> 8));  // branch-free: one pointer, one load
+        j_b[r] = tab.lo[direct ? 0u : (jj & 255u)];
     }
     MCMCPP_DSTAMP(5, false);  // raw outputs computed, gathers issued
 #pragma unroll
@@ -594,8 +684,8 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         if (wib == kWavesPerBlock)
         {
             // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-            draw_wave_body<T, 2>(a, hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0, h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count,
-                                 blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
+            draw_wave_body<T, 2>(a, jump_tables_behind(hot_draws, hot_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0,
+                                 h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
             return;
         }
     }
@@ -933,7 +1023,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         if ((threadIdx.x >> 6) == kWavesPerBlock)
         {
             // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-            draw_wave_body<T, 2>(a, hot_ctl_in, true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
+            draw_wave_body<T, 2>(a, jump_tables_behind(hot_draws, hot_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in,
+                                 true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
                                  h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane);
             return;
         }
