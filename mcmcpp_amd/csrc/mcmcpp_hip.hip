@@ -446,6 +446,7 @@ public:
         HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(Diag), stream));
         half_steps = 0;
         steps_since_reset = 0;
+        records_valid = false;
         int rc = write_ctl(0);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
@@ -502,6 +503,8 @@ public:
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
+        records_valid = false;  // (until this call has finished: an error on the way leaves them unknown)
+        run_info_idle = false;
         if (full_fn)
         {
             hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, d_nacc, W, kRowMovedBit);
@@ -605,15 +608,15 @@ public:
             last_launches = full_fn ? total : 2 * total;
             half_steps += 2 * (uint64_t)total;
             steps_since_reset += (uint64_t)total;
+            // the last launch left the records of the next ensemble step behind (full-step launches: with partner2)
+            records_valid = true;
+            records_step = half_steps >> 1;
+            records_partner2 = full_fn != nullptr;
             if (accepted_per_step)
                 HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
         }
         const auto tp3 = std::chrono::steady_clock::now();
-        {
-            // leave no pointer to run-scoped buffers in the device-side RunInfo
-            const int rc2 = upload_idle_run_info();
-            if (rc == MCMCPP_HIP_OK) rc = rc2;
-        }
+        // (the device-side RunInfo still points to run-scoped buffers; half_step_async replaces it before it launches)
         if (dbg)
         {
             const auto tp4 = std::chrono::steady_clock::now();
@@ -727,6 +730,7 @@ public:
         if (steps_done > (~0ULL >> 2)) return fail(MCMCPP_HIP_E_ARG, "seek: step count out of range");
         HIP_TRY(hipSetDevice(device));
         half_steps = 2 * steps_done;
+        records_valid = false;
         return write_ctl(0);  // repositions the stream and re-primes the draw records of the next two half-steps
     }
 
@@ -797,6 +801,11 @@ public:
         if (save_slot >= 0 && (!bound_chain || save_slot >= bound_slots))
             return fail(MCMCPP_HIP_E_ARG, "half_step_async: save_slot outside the bound device chain");
         HIP_TRY(hipSetDevice(device));
+        if (!run_info_idle)
+        {
+            const int rc = upload_idle_run_info();
+            if (rc) return rc;
+        }
         HalfStepArgs<T> a = make_args(color, (int)((half_steps >> 1) & 1));
         a.use_ctl_save = 0;
         a.partials = nullptr;
@@ -805,6 +814,10 @@ public:
         HIP_TRY(hipGetLastError());
         half_steps += 1;
         if (color == 1) steps_since_reset += 1;
+        // the two launches of a step leave the next step's records of this handle's shard behind (without partner2)
+        records_valid = color == 1 && shard_count == n;
+        records_step = half_steps >> 1;
+        records_partner2 = false;
         return MCMCPP_HIP_OK;
     }
 
@@ -863,6 +876,7 @@ private:
         ri.step_bytes = 0;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(d_run, &ri, sizeof ri, hipMemcpyHostToDevice));
+        run_info_idle = true;
         return MCMCPP_HIP_OK;
     }
 
@@ -948,11 +962,18 @@ private:
         c->save_phase = 0;
         c->partial_slot = 0;
         HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
-        // the draw records of the next red and the next black half-step (afterwards the launches keep them going)
-        const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
-        launch_fill_draws(make_args(0, parity), c->state, nullptr, stream);
-        launch_fill_draws(make_args(1, parity), state1, full_fn ? &c->state : nullptr, stream);
-        HIP_TRY(hipGetLastError());
+        // the draw records of the next red and the next black half-step (afterwards the launches keep them going):
+        // unless the launches of the previous call left exactly these behind
+        if (!(records_valid && records_step == (half_steps >> 1) && (!full_fn || records_partner2)))
+        {
+            const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
+            launch_fill_draws(make_args(0, parity), c->state, nullptr, stream);
+            launch_fill_draws(make_args(1, parity), state1, full_fn ? &c->state : nullptr, stream);
+            HIP_TRY(hipGetLastError());
+            records_valid = true;
+            records_step = half_steps >> 1;
+            records_partner2 = full_fn != nullptr;
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         return MCMCPP_HIP_OK;
     }
@@ -1177,6 +1198,9 @@ private:
     int partial_slots = 1, partial_waves = 0;
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_task_jump = nullptr;  // behind d_draws: see JumpTables
     bool have_task_table = false;
+    // which ensemble step the draw records on the device belong to, if known, and whether the black ones carry partner2
+    bool records_valid = false, records_partner2 = false, run_info_idle = false;
+    uint64_t records_step = 0;
     void* h_pinned = nullptr;
     U128 state0, inc;
     Affine128 half_jump;
