@@ -21,9 +21,11 @@
 //            (record, row, log-posterior) AND x's own partner row -- the black record carries that index
 //            (DrawRec::partner2: the draws do not depend on the walkers, so whoever makes the black record can
 //            repeat x's partner draw)
-//   then     x's update repeated, the black update against its result; the red owner's update fills the gaps.
-// Draw records one step ahead (two extra wavefronts per workgroup, one per colour), counters, chain stores: as
-// in stretch_kernel.hpp.
+//   then     x's update repeated (together with the red owner's own), the black update against its result.
+// Every scalar miss of an updating wavefront (control record, run record, the lines of the launch description) is
+// taken in ONE batch behind the second trip's loads (load_records_and_warm_args).  Draw records one step ahead
+// (four extra wavefronts per workgroup, two per colour), counters, chain stores: as in stretch_kernel.hpp; stored
+// steps reach pinned host memory through the launches themselves (trickle_stored_step).
 #pragma once
 
 #include "stretch_kernel.hpp"
