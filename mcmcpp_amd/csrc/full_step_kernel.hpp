@@ -399,9 +399,6 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         nacc_r[q] = h_n_accept[ir[q]];
         nacc_b[q] = h_n_accept[h_n + ir[q]];
     }
-    McB matB;
-    mc_load_b(hot_matrix, sub, grp, matB);  // 8 x 16 bytes per lane, the same 8 KiB for every wavefront: L2 hits; the pointer is
-                                            // a preloaded argument: no kernarg miss in front of these loads or of the second trip
 
     // ---- second round trip: everything the records point to ----
     T par_r[2][2], own_x[2][2], par_x[2][2], lp_x[2];
@@ -416,6 +413,12 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         lp_x[q] = lin[jx];
         load_row(pin, h_n + (int)rec_b[q].partner2, par_x[q]);
     }
+    // The wavefront's share of P^T: 8 x 16 bytes per lane, the same 8 KiB for every wavefront (L2 hits), through a preloaded
+    // pointer (no kernarg miss in front).  Behind the second trip's loads on purpose: issued with the first trip they
+    // compete with every wavefront's record loads, which the second trip waits for (5.76 -> 5.60 us per launch).
+    asm volatile("" ::: "memory");
+    McB matB;
+    mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);
     // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
     StepCtl ctl;
