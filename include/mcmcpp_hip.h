@@ -197,6 +197,24 @@ int mcmcpp_hip_moments_add_device_steps(mcmcpp_hip_moments* m, const void* devic
 int mcmcpp_hip_moments_finish(mcmcpp_hip_moments* m, int64_t* num_points, void* mean, void* cov, void* corr);
 const char* mcmcpp_hip_moments_last_error(const mcmcpp_hip_moments* m);
 
+/* Analysis::AutoCorrCalc::calcAutoCorrTimes (reference MCMCpp/Analysis/AutoCorrCalc.h:151-207, with
+ * Analysis/Detail/AutoCov.h:146-322): the integrated autocorrelation time of every parameter.  Per (walker, parameter)
+ * series: Kahan average, circular autocovariance by two radix-2 FFTs over the next power of two >= n_steps, divided by
+ * lag 0; per parameter: the walkers' functions Kahan-summed and divided by their number, then the windowed sum
+ * (window_scaling = the reference's setAutoCorrScaleFactor value, default 4).  One workgroup per series, transforms in LDS.
+ *   steps          n_steps pointers to stored steps of num_walkers*num_params elements (host memory), oldest first
+ *   walkers_to_use 0 = all; otherwise that many walkers, evenly spaced over the ensemble (the reference draws a
+ *                  subset seeded from std::random_device, i.e. irreproducibly)
+ *   times          [num_params]: the time, or minus the final sum where the window never closed (as the reference)
+ *   functions      NULL, or [num_params][n_steps]: the averaged autocovariance functions
+ * Every operation is the reference's own expression in the reference's order (twiddle factors from the host's libm):
+ * results are bit-identical to the oracle's restatement, which is pinned bit for bit to the reference's AutoCov.  Not
+ * reproduced: the reference's transferWalker ADDS each series onto what its scratch array holds (the previous
+ * walker's function; uninitialised memory for the first), see INTEGRATION.md 4b. */
+int mcmcpp_hip_autocorr_times(int32_t dtype, int32_t device, const void* const* steps, int64_t n_steps, int32_t num_walkers, int32_t num_params,
+                              int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions);
+const char* mcmcpp_hip_autocorr_last_error(void);
+
 int mcmcpp_hip_abi_version(void);
 
 #ifdef __cplusplus

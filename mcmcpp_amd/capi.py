@@ -21,6 +21,7 @@ EXPORTS = [
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
     "mcmcpp_hip_moments_create", "mcmcpp_hip_moments_destroy", "mcmcpp_hip_moments_reset", "mcmcpp_hip_moments_add_steps",
     "mcmcpp_hip_moments_add_device_steps", "mcmcpp_hip_moments_finish", "mcmcpp_hip_moments_last_error",
+    "mcmcpp_hip_autocorr_times", "mcmcpp_hip_autocorr_last_error",
 ]
 
 
@@ -93,6 +94,10 @@ def lib():
             L.mcmcpp_hip_moments_finish.argtypes = [vp, C.POINTER(i64), vp, vp, vp]
             L.mcmcpp_hip_moments_last_error.argtypes = [vp]
             L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
+        if hasattr(L, "mcmcpp_hip_autocorr_times"):
+            L.mcmcpp_hip_autocorr_times.argtypes = [i32, i32, C.POINTER(vp), i64, i32, i32, i32, i32, vp, vp]
+            L.mcmcpp_hip_autocorr_last_error.argtypes = []
+            L.mcmcpp_hip_autocorr_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -247,3 +252,31 @@ class HipMoments:
             self.close()
         except Exception:
             pass
+
+
+def autocorr_times(steps, walkers_to_use=0, window_scaling=4, want_functions=False, dtype=None, device=-1):
+    """Device-side Analysis::AutoCorrCalc::calcAutoCorrTimes (include/mcmcpp_hip.h, mcmcpp_hip_autocorr_times).
+
+    steps: array [(n, W, D)] or a sequence of n arrays [(W, D)] (stored steps, oldest first).  Returns times[D], or
+    (times, functions[(D, n)]) with want_functions."""
+    if isinstance(steps, np.ndarray):
+        if dtype is None:
+            dtype = F32 if steps.dtype == np.float32 else F64
+        steps = np.ascontiguousarray(steps, dtype=np_dtype(dtype))
+        assert steps.ndim == 3
+        blocks = [steps[i] for i in range(steps.shape[0])]
+    else:
+        if dtype is None:
+            dtype = F32 if np.asarray(steps[0]).dtype == np.float32 else F64
+        blocks = [np.ascontiguousarray(b, dtype=np_dtype(dtype)) for b in steps]
+    n = len(blocks)
+    W, D = blocks[0].shape
+    assert all(b.shape == (W, D) for b in blocks)
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in blocks])
+    t = np_dtype(dtype)
+    times = np.zeros(D, t)
+    functions = np.zeros((D, n), t) if want_functions else None
+    rc = lib().mcmcpp_hip_autocorr_times(dtype, device, ptrs, n, W, D, walkers_to_use, window_scaling, _ptr(times), _ptr(functions))
+    if rc != OK:
+        raise HipError(rc, (lib().mcmcpp_hip_autocorr_last_error() or b"").decode())
+    return (times, functions) if want_functions else times

@@ -71,6 +71,8 @@ def lib():
         L.so_half_step_commit.argtypes = [C.c_void_p]
         L.so_chain_covariance.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                           C.c_void_p, C.c_void_p]
+        L.so_norm_autocov.argtypes = [C.c_int32, C.c_void_p, C.c_double, C.c_int32]
+        L.so_autocorr_times.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.so_positions_ptr.argtypes = [C.c_void_p]
         L.so_positions_ptr.restype = C.c_void_p
         L.so_logp_ptr.argtypes = [C.c_void_p]
@@ -229,6 +231,8 @@ def ref_lib():
                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
                               C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         R.ref_chain_covariance.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        R.ref_norm_autocov.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int]
+        R.ref_autocorr_times.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
         R.ref_skewed_initial_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
         R.ref_skewed_initial_values.restype = None
         _ref = R
@@ -276,6 +280,28 @@ def chain_covariance(steps, slice_interval=1):
     return mean, cov, corr
 
 
+def norm_autocov(series, avg, dtype=F64):
+    """Restatement of Analysis::Detail::AutoCov::calcNormAutoCov on one series."""
+    x = np.array(series, dtype=np_dtype(dtype))
+    rc = lib().so_norm_autocov(dtype, _ptr(x), float(avg), x.size)
+    if rc:
+        raise ValueError("so_norm_autocov failed: %d" % rc)
+    return x
+
+
+def autocorr_times(steps, window_scaling=4, emulate_defect=False, dtype=F64, want_functions=False):
+    """Restatement of Analysis::AutoCorrCalc::calcAutoCorrTimes (all walkers) over steps[n][W][D] -> [D]
+    (with want_functions: also the averaged autocovariance functions [D][n])."""
+    steps = np.ascontiguousarray(steps, dtype=np_dtype(dtype))
+    n, W, D = steps.shape
+    out = np.zeros(D, steps.dtype)
+    fn = np.zeros((D, n), steps.dtype) if want_functions else None
+    rc = lib().so_autocorr_times(dtype, _ptr(steps), n, W, D, window_scaling, int(bool(emulate_defect)), _ptr(out), _ptr(fn))
+    if rc:
+        raise ValueError("so_autocorr_times failed: %d" % rc)
+    return (out, fn) if want_functions else out
+
+
 def reference_chain_covariance(steps, slice_interval=1):
     """The reference's own Analysis::CovarianceMatrix over its own Chain holding `steps`: (cov, corr)."""
     steps = np.ascontiguousarray(steps)
@@ -287,6 +313,24 @@ def reference_chain_covariance(steps, slice_interval=1):
     if rc:
         raise ValueError("ref_chain_covariance failed: %d" % rc)
     return cov, corr
+
+
+def reference_norm_autocov(series, avg, dtype=F64):
+    """Analysis::Detail::AutoCov::calcNormAutoCov of the reference on one series."""
+    x = np.array(series, dtype=np_dtype(dtype))
+    ref_lib().ref_norm_autocov(dtype, _ptr(x), float(avg), x.size)
+    return x
+
+
+def reference_autocorr_times(steps, window_scaling=4, dtype=F64):
+    """Analysis::AutoCorrCalc::calcAutoCorrTimes of the reference (all walkers) over steps[n][W][D]."""
+    steps = np.ascontiguousarray(steps, dtype=np_dtype(dtype))
+    n, W, D = steps.shape
+    out = np.zeros(D, steps.dtype)
+    rc = ref_lib().ref_autocorr_times(dtype, _ptr(steps), n, W, D, window_scaling, _ptr(out))
+    if rc:
+        raise ValueError("ref_autocorr_times failed: %d" % rc)
+    return out
 
 
 def reference_skewed_initial_values(W=320, eps=0.13, extra_run_number=53):

@@ -25,6 +25,7 @@ using arrow_vendored::pcg64;
 #include "ParallelEnsembleSampler.h"
 #include "Common/SkewedGaussian.h"
 #include "Analysis/CovarianceMatrix.h"
+#include "Analysis/AutoCorrCalc.h"
 
 #include "../include/MCMCpp/Device/Calculators.h"
 
@@ -146,6 +147,26 @@ static int refCovariance(const T* steps, long long n_steps, int W, int D, int sl
     return 0;
 }
 
+/* The reference's Analysis::AutoCorrCalc over a chain given as [n_steps][W][D], all walkers used.  Its scratch array
+ * comes from new[] uninitialised and transferWalker adds onto it (AutoCorrCalc.h:239-245,307-320): results are only
+ * defined when that memory happens to be zero, which holds for arrays big enough to come straight from mmap
+ * (n_steps >= 32768 values here). */
+template <class T>
+static int refAutoCorr(const T* steps, long long n_steps, int W, int D, int window_scaling, T* out)
+{
+    MCMC::Chain::Chain<T> chain(W, D, static_cast<unsigned long long>(n_steps + 1) * W * D * sizeof(T) + (1ull << 20));
+    for (long long s = 0; s < n_steps; ++s)
+    {
+        for (int w = 0; w < W; ++w) chain.storeWalker(w, const_cast<T*>(steps + (static_cast<size_t>(s) * W + w) * D));
+        chain.incrementChainStep();
+    }
+    MCMC::Analysis::AutoCorrCalc<T> ac(D, W);
+    ac.setAutoCorrScaleFactor(window_scaling);
+    ac.calcAutoCorrTimes(chain.getStepIteratorBegin(), chain.getStepIteratorEnd(), static_cast<int>(n_steps));
+    for (int i = 0; i < D; ++i) out[i] = ac.retrieveAutoCorrelationTime(i);
+    return 0;
+}
+
 }  // namespace
 
 extern "C"
@@ -176,6 +197,28 @@ int ref_chain_covariance(int dtype, const void* steps, long long n_steps, int W,
     if (dtype == 0)
         return refCovariance<double>(static_cast<const double*>(steps), n_steps, W, D, slice, static_cast<double*>(cov), static_cast<double*>(corr));
     return refCovariance<float>(static_cast<const float*>(steps), n_steps, W, D, slice, static_cast<float*>(cov), static_cast<float*>(corr));
+}
+
+/* Analysis::Detail::AutoCov::calcNormAutoCov on one series, in place */
+int ref_norm_autocov(int dtype, void* chain, double avg, int n)
+{
+    if (dtype == 0)
+    {
+        MCMC::Analysis::Detail::AutoCov<double> ac;
+        ac.calcNormAutoCov(static_cast<double*>(chain), avg, n);
+    }
+    else
+    {
+        MCMC::Analysis::Detail::AutoCov<float> ac;
+        ac.calcNormAutoCov(static_cast<float*>(chain), static_cast<float>(avg), n);
+    }
+    return 0;
+}
+
+int ref_autocorr_times(int dtype, const void* steps, long long n_steps, int W, int D, int window_scaling, void* out)
+{
+    if (dtype == 0) return refAutoCorr<double>(static_cast<const double*>(steps), n_steps, W, D, window_scaling, static_cast<double*>(out));
+    return refAutoCorr<float>(static_cast<const float*>(steps), n_steps, W, D, window_scaling, static_cast<float*>(out));
 }
 
 /* Initial walker placement of the reference's SkewedGaussian/StretchMove test

@@ -4,6 +4,7 @@
  *
  * Every function names the reference lines it follows (paths relative to /root/reference).
  */
+#define _GNU_SOURCE /* sincos, sincosf */
 #include "stretch_oracle.h"
 
 #include <math.h>
@@ -145,6 +146,7 @@ struct so_sampler {
 #define SFX(n) n##_f64
 #define LOG(x) log(x)
 #define SQRT(x) sqrt(x)
+#define SINCOS(x, s, c) sincos(x, s, c)
 #define FMA(a, b, c) fma(a, b, c)
 #define FABS(x) fabs(x)
 #define CANON(r) so_canonical_f64(r)
@@ -154,6 +156,7 @@ struct so_sampler {
 #undef SFX
 #undef LOG
 #undef SQRT
+#undef SINCOS
 #undef FMA
 #undef FABS
 #undef CANON
@@ -163,6 +166,7 @@ struct so_sampler {
 #define SFX(n) n##_f32
 #define LOG(x) logf(x)
 #define SQRT(x) sqrtf(x)
+#define SINCOS(x, s, c) sincosf(x, s, c)
 #define FMA(a, b, c) fmaf(a, b, c)
 #define FABS(x) fabsf(x)
 #define CANON(r) so_canonical_f32(r)
@@ -172,6 +176,7 @@ struct so_sampler {
 #undef SFX
 #undef LOG
 #undef SQRT
+#undef SINCOS
 #undef FMA
 #undef FABS
 #undef CANON
@@ -311,6 +316,42 @@ int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32
         chain_covariance_f64((const double*)steps, n_steps, walkers, dims, slice, (double*)mean, (double*)cov, (double*)corr);
     else if (dtype == SO_F32)
         chain_covariance_f32((const float*)steps, n_steps, walkers, dims, slice, (float*)mean, (float*)cov, (float*)corr);
+    else
+        return -1;
+    return 0;
+}
+
+int so_norm_autocov(int32_t dtype, void* chain, double avg, int32_t n)
+{
+    if (!chain || n < 2 || (dtype != SO_F64 && dtype != SO_F32)) return -1;
+    if (dtype == SO_F64) {
+        const int lg = fft_log2_f64(n), fft = 1 << lg;
+        double* tw = (double*)malloc(sizeof(double) * (size_t)fft);
+        double* work = (double*)malloc(sizeof(double) * 4 * (size_t)fft);
+        fft_twiddles_f64(lg, tw);
+        norm_autocov_f64((double*)chain, avg, n, lg, tw, work);
+        free(tw);
+        free(work);
+    } else {
+        const int lg = fft_log2_f32(n), fft = 1 << lg;
+        float* tw = (float*)malloc(sizeof(float) * (size_t)fft);
+        float* work = (float*)malloc(sizeof(float) * 4 * (size_t)fft);
+        fft_twiddles_f32(lg, tw);
+        norm_autocov_f32((float*)chain, (float)avg, n, lg, tw, work);
+        free(tw);
+        free(work);
+    }
+    return 0;
+}
+
+int so_autocorr_times(int32_t dtype, const void* steps, int32_t n_steps, int32_t walkers, int32_t dims, int32_t window_scaling,
+                      int32_t emulate_defect, void* out, void* functions)
+{
+    if (!steps || !out || n_steps < 2 || walkers < 1 || dims < 1) return -1;
+    if (dtype == SO_F64)
+        autocorr_times_f64((const double*)steps, n_steps, walkers, dims, window_scaling, emulate_defect, (double*)out, (double*)functions);
+    else if (dtype == SO_F32)
+        autocorr_times_f32((const float*)steps, n_steps, walkers, dims, window_scaling, emulate_defect, (float*)out, (float*)functions);
     else
         return -1;
     return 0;

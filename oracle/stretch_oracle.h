@@ -106,6 +106,14 @@ int so_calc_logp(const so_config* cfg, const void* x, void* out);
 int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32_t walkers, int32_t dims, int32_t slice,
                         void* mean, void* cov, void* corr);
 
+/* Analysis::Detail::AutoCov::calcNormAutoCov (Analysis/Detail/AutoCov.h:146-155): chain[n] in, normalised circular
+ * autocovariance out; and Analysis::AutoCorrCalc::calcAutoCorrTimes with all walkers (Analysis/AutoCorrCalc.h:151-207)
+ * over steps[n][walkers][dims] -> out[dims].  emulate_defect: 1 restates the reference to the letter (its transferWalker
+ * adds each series onto the previous walker's result), 0 is the documented computation (see the .inc). */
+int so_norm_autocov(int32_t dtype, void* chain, double avg, int32_t n);
+int so_autocorr_times(int32_t dtype, const void* steps, int32_t n_steps, int32_t walkers, int32_t dims, int32_t window_scaling,
+                      int32_t emulate_defect, void* out, void* functions /* NULL or [dims][n_steps]: the averaged functions */);
+
 /* --- pcg64 (setseq_xsl_rr_128_64) primitives, exposed for known-answer tests ------------------- */
 typedef struct so_pcg64 {
     uint64_t state_hi, state_lo;

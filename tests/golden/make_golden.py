@@ -161,8 +161,55 @@ def make_covariance():
     return out
 
 
+AUTOCORR_CLASS = {  # name: (n, W, D, seed, phi, window_scaling, dtype)
+    "autocorr_class_f64": (40000, 4, 2, 11, (0.9, 0.5), 4, po.F64),
+    "autocorr_class_f32": (36000, 3, 2, 12, (0.8, 0.3), 5, po.F32),
+}
+
+
+def make_autocorr(which=None):
+    """Analysis::Detail::AutoCov and Analysis::AutoCorrCalc of the reference.
+
+    autocov_series.npz: series, their averages and the reference's calcNormAutoCov output.
+    autocorr_class_*.npz: the reference's calcAutoCorrTimes over a chain from tests/goldens.ar_chain (only its
+    parameters and a digest are stored).  The class adds every series onto the scratch array it allocates
+    uninitialised (AutoCorrCalc.h:239-245,307-320): its output is only defined when that memory is zero, hence the
+    long chains and one class fixture per process (which=...), run with MALLOC_MMAP_THRESHOLD_=65536 so that glibc takes
+    the array straight from mmap."""
+    from tests.goldens import ar_chain
+    out = []
+    if which is None:
+        data = {}
+        for tag, (n, seed, phi, dtype) in {"f64_n100": (100, 1, 0.7, po.F64), "f64_n1000": (1000, 2, 0.95, po.F64), "f64_n1024": (1024, 3, 0.5, po.F64),
+                                           "f64_n1025": (1025, 4, 0.9, po.F64), "f64_n3": (3, 5, 0.2, po.F64), "f32_n777": (777, 6, 0.85, po.F32),
+                                           "f32_n2048": (2048, 7, 0.6, po.F32)}.items():
+            x = ar_chain(n, 1, 1, seed, phi, po.np_dtype(dtype)).ravel()
+            avg = po.np_dtype(dtype)(x.astype(np.float64).mean())
+            data[tag + "_series"] = x
+            data[tag + "_avg"] = np.array(avg)
+            data[tag + "_autocov"] = po.reference_norm_autocov(x, float(avg), dtype)
+        path = os.path.join(HERE, "autocov_series.npz")
+        np.savez_compressed(path, **data)
+        out.append(dict(name="autocov_series", bytes=os.path.getsize(path)))
+        for name in AUTOCORR_CLASS:  # one fresh process each
+            import subprocess
+            # MALLOC_MMAP_THRESHOLD_: glibc then serves every array above 64 KiB from fresh (zero) pages
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "autocorr:" + name], env=dict(os.environ, MALLOC_MMAP_THRESHOLD_="65536"))
+        return out
+    n, W, D, seed, phi, scaling, dtype = AUTOCORR_CLASS[which]
+    steps = ar_chain(n, W, D, seed, phi, po.np_dtype(dtype))
+    times = po.reference_autocorr_times(steps, scaling, dtype)
+    assert np.all(np.isfinite(times)), "the reference's scratch memory was not zero: %r" % (times,)
+    path = os.path.join(HERE, which + ".npz")
+    np.savez_compressed(path, n=n, W=W, D=D, seed=seed, phi=np.array(phi), window_scaling=scaling, dtype=dtype, steps_sha256=sha(steps), times=times)
+    return [dict(name=which, times=times.tolist(), bytes=os.path.getsize(path))]
+
+
 def main():
     want = sys.argv[1:]
+    if want and want[0].startswith("autocorr:"):
+        print(make_autocorr(want[0].split(":", 1)[1]), flush=True)
+        return
     if not po.reference_available():
         sys.exit("oracle/_ref/libmcmcpp_ref.so is not available (no /root/reference here)")
     summary = []
@@ -175,6 +222,8 @@ def main():
         print(make_reference_test_run(), flush=True)
     if not want or "covariance" in want:
         print(make_covariance(), flush=True)
+    if not want or "autocorr" in want:
+        print(make_autocorr(), flush=True)
     if not want:
         with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
             json.dump(summary, f, indent=1)

@@ -58,3 +58,23 @@ class Golden:
     @property
     def checked_steps(self):
         return self.full_steps + self.digest_steps
+
+
+def ar_chain(n, W, D, seed, phi, dtype=np.float64):
+    """Deterministic [n][W][D] chain for the analysis tests: every (walker, parameter) series is an AR(1) process
+    x_t = phi[p] x_{t-1} + e_t whose innovations come from a splitmix64-style integer hash (uniform on [-1, 1)); integer
+    arithmetic and one multiply-add per element, so every platform produces the same bytes (pinned by digests in the
+    fixtures that use it)."""
+    idx = np.arange(n * W * D, dtype=np.uint64).reshape(n, W, D)
+    with np.errstate(over="ignore"):
+        z = (idx + np.uint64(seed)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    e = (z >> np.uint64(11)).astype(np.float64) * (2.0 / 9007199254740992.0) - 1.0
+    phi = np.broadcast_to(np.asarray(phi, dtype=np.float64), (D,))
+    x = np.empty((n, W, D), dtype=np.float64)
+    x[0] = e[0]
+    for t in range(1, n):
+        x[t] = phi * x[t - 1] + e[t]
+    return np.ascontiguousarray(x.astype(dtype))
