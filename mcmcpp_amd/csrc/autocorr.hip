@@ -257,11 +257,11 @@ int autocorr_times(const void* const* steps, int64_t n_steps, int W, int D, int 
 
     DeviceBuffers dev;
     AC_TRY(hipStreamCreateWithFlags(&dev.stream, hipStreamNonBlocking));
-    // walkers per pass over the transforms: bounded by 256 MiB of functions and 512 MiB of global scratch
+    // walkers per pass over the transforms: bounded by 1 GiB of functions and 2 GiB of global scratch
     size_t per_walker = sizeof(T) * (size_t)D * n;
     size_t per_walker_scratch = lds ? 0 : sizeof(T) * (size_t)D * 2 * fft;
     int chunk = use;
-    while (chunk > 1 && ((size_t)chunk * per_walker > ((size_t)256 << 20) || (size_t)chunk * per_walker_scratch > ((size_t)512 << 20))) chunk = (chunk + 1) / 2;
+    while (chunk > 1 && ((size_t)chunk * per_walker > ((size_t)1 << 30) || (size_t)chunk * per_walker_scratch > ((size_t)2 << 30))) chunk = (chunk + 1) / 2;
 
     T *d_steps, *d_avg, *d_tw, *d_acov, *d_sum, *d_comp, *d_times, *d_scratch = nullptr;
     int* d_idx;

@@ -73,6 +73,7 @@ def lib():
                                           C.c_void_p, C.c_void_p]
         L.so_norm_autocov.argtypes = [C.c_int32, C.c_void_p, C.c_double, C.c_int32]
         L.so_autocorr_times.argtypes = [C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.so_ar1_test_chain.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so_positions_ptr.argtypes = [C.c_void_p]
         L.so_positions_ptr.restype = C.c_void_p
         L.so_logp_ptr.argtypes = [C.c_void_p]
@@ -233,6 +234,7 @@ def ref_lib():
         R.ref_chain_covariance.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         R.ref_norm_autocov.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int]
         R.ref_autocorr_times.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        R.ref_actime_test.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         R.ref_skewed_initial_values.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int]
         R.ref_skewed_initial_values.restype = None
         _ref = R
@@ -331,6 +333,37 @@ def reference_autocorr_times(steps, window_scaling=4, dtype=F64):
     if rc:
         raise ValueError("ref_autocorr_times failed: %d" % rc)
     return out
+
+
+# the reference's AutoCorrCalc known-answer test (test/sequential/AcTime/src/main.cpp:23-34): five AR(1) parameters with
+# analytic times 9, 20, 30, 60, 200; 100 walkers, 262143 steps, run number 0; its recorded outputs (main.cpp:16-22)
+ACTIME_PHIS = (0.8, 0.904761904762, 0.9354838709677, 0.9672131147541, 0.990050200903734685)
+ACTIME_RECORDED = (9.01951, 19.9437, 29.7831, 59.8488, 196.85)
+ACTIME_WALKERS, ACTIME_STEPS = 100, 262143
+
+
+def ar1_test_chain(n_steps, W=ACTIME_WALKERS, phis=ACTIME_PHIS, run_number=0):
+    """Restatement of the chain of the reference's AcTime test: [n_steps + 1][W][D] (offsets 1, variances 1)."""
+    D = len(phis)
+    chain = np.empty((n_steps + 1, W, D), dtype=np.float64)
+    ones = np.ones(D)
+    ph = np.array(phis, dtype=np.float64)
+    rc = lib().so_ar1_test_chain(run_number, W, D, n_steps, _ptr(ones), _ptr(ph), _ptr(ones), _ptr(chain))
+    if rc:
+        raise ValueError("so_ar1_test_chain failed: %d" % rc)
+    return chain
+
+
+def reference_actime_test(n_steps, W=ACTIME_WALKERS, phis=ACTIME_PHIS, run_number=0, want_chain=True):
+    """The reference's AcTime test run by the reference itself: (chain or None, times[D])."""
+    D = len(phis)
+    chain = np.empty((n_steps + 1, W, D), dtype=np.float64) if want_chain else None
+    times = np.zeros(D)
+    ones = np.ones(D)
+    ph = np.array(phis, dtype=np.float64)
+    stored = ref_lib().ref_actime_test(run_number, W, D, n_steps, _ptr(ones), _ptr(ph), _ptr(ones), _ptr(chain), _ptr(times))
+    assert stored == n_steps + 1, stored
+    return chain, times
 
 
 def reference_skewed_initial_values(W=320, eps=0.13, extra_run_number=53):

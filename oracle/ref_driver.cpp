@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstring>
 #include <random>
+#include <vector>
 
 // pcg-cpp: un-vendored submodule of the reference; the image's copy lives in namespace arrow_vendored.
 #include PCG_HEADER
@@ -26,6 +27,7 @@ using arrow_vendored::pcg64;
 #include "Common/SkewedGaussian.h"
 #include "Analysis/CovarianceMatrix.h"
 #include "Analysis/AutoCorrCalc.h"
+#include "Movers/Diagnostic/AutoRegressiveMove.h"
 
 #include "../include/MCMCpp/Device/Calculators.h"
 
@@ -219,6 +221,30 @@ int ref_autocorr_times(int dtype, const void* steps, long long n_steps, int W, i
 {
     if (dtype == 0) return refAutoCorr<double>(static_cast<const double*>(steps), n_steps, W, D, window_scaling, static_cast<double*>(out));
     return refAutoCorr<float>(static_cast<const float*>(steps), n_steps, W, D, window_scaling, static_cast<float*>(out));
+}
+
+/* The reference's AutoCorrCalc known-answer test (test/sequential/AcTime/src/main.cpp:23-82) with its statements in its
+ * order: mover, sampler, initial points from the test's own mover object, runMCMC, AutoCorrCalc over all stored steps.
+ * chain_out: NULL or [n_steps + 1][W][D]; times_out: [D]. */
+int ref_actime_test(int run_number, int W, int D, int n_steps, const double* offsets, const double* phis, const double* vars, double* chain_out,
+                    double* times_out)
+{
+    MCMC::Mover::AutoRegressiveMove<double> mover(D, offsets, phis, vars);
+    MCMC::EnsembleSampler<double, MCMC::Mover::AutoRegressiveMove<double> > sampler(run_number, W, D, mover);
+    std::vector<double> init(static_cast<size_t>(W) * D), aux(W);
+    mover.getInitialPoints(init.data(), aux.data(), W);
+    sampler.setInitialWalkerPos(init.data(), aux.data());
+    sampler.runMCMC(n_steps);
+    if (chain_out)
+    {
+        size_t k = 0;
+        for (auto it = sampler.getStepIttBegin(); it != sampler.getStepIttEnd(); ++it, ++k)
+            std::memcpy(chain_out + k * W * D, *it, sizeof(double) * static_cast<size_t>(W) * D);
+    }
+    MCMC::Analysis::AutoCorrCalc<double> ac(D, W);
+    ac.calcAutoCorrTimes(sampler.getStepIttBegin(), sampler.getStepIttEnd(), sampler.getStoredSteps());
+    for (int i = 0; i < D; ++i) times_out[i] = ac.retrieveAutoCorrelationTime(i);
+    return sampler.getStoredSteps();
 }
 
 /* Initial walker placement of the reference's SkewedGaussian/StretchMove test

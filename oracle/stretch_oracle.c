@@ -321,6 +321,72 @@ int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32
     return 0;
 }
 
+/* std::normal_distribution<double>(0, 1) over pcg64 as libstdc++ implements it (bits/random.tcc:1802-1835, GCC 11): the
+ * polar method, two canonical draws per attempt, the second variate kept for the next call. */
+typedef struct { so_pcg64 eng; int have; double saved; } normal_src;
+static double normal_next(normal_src* g)
+{
+    double ret;
+    if (g->have) {
+        g->have = 0;
+        ret = g->saved;
+    } else {
+        double x, y, r2;
+        do {
+            x = 2.0 * so_canonical_f64(so_pcg64_next(&g->eng)) - 1.0;
+            y = 2.0 * so_canonical_f64(so_pcg64_next(&g->eng)) - 1.0;
+            r2 = x * x + y * y;
+        } while (r2 > 1.0 || r2 == 0.0);
+        const double mult = sqrt(-2 * log(r2) / r2);
+        g->saved = x * mult;
+        g->have = 1;
+        ret = y * mult;
+    }
+    return ret * 1.0 + 0.0;
+}
+
+/* The chain of the reference's AutoCorrCalc known-answer test (test/sequential/AcTime/src/main.cpp:23-52): W walkers of
+ * D independent AR(1) parameters moved by Mover::AutoRegressiveMove (Movers/Diagnostic/AutoRegressiveMove.h:78-105).
+ * Initial points come from the test's own mover object, whose engine is pcg64(0) on the DEFAULT stream
+ * (AutoRegressiveMove.h:55, MultiSampler.h:42), parameter by parameter; the steps from the sampler's copy of it, reseeded
+ * to (run_number, stream 0) (EnsembleSampler.h:217), walkers in order 0..W-1 (red set then black set,
+ * EnsembleSampler.h:342-354), D normal variates each.  chain: [n_steps + 1][W][D], step 0 = the initial points. */
+int so_ar1_test_chain(int32_t run_number, int32_t W, int32_t D, int32_t n_steps, const double* offsets, const double* phis,
+                      const double* vars, double* chain)
+{
+    if (!offsets || !phis || !vars || !chain || W < 1 || D < 1 || n_steps < 0) return -1;
+    double* sd = (double*)malloc(sizeof(double) * (size_t)D);
+    if (!sd) return -7;
+    for (int i = 0; i < D; ++i) sd[i] = sqrt(vars[i]) * sqrt(1.0 - phis[i] * phis[i]);
+    normal_src init;
+    memset(&init, 0, sizeof init);
+    { /* pcg64 engine(0) without a stream argument: the 128-bit default increment */
+        const u128 inc = mk128(6364136223846793005ULL, 1442695040888963407ULL);
+        const u128 st = ((u128)0 + inc) * pcg_mult() + inc;
+        init.eng.state_hi = (uint64_t)(st >> 64);
+        init.eng.state_lo = (uint64_t)st;
+        init.eng.inc_hi = (uint64_t)(inc >> 64);
+        init.eng.inc_lo = (uint64_t)inc;
+    }
+    for (int i = 0; i < D; ++i) {
+        const double total = sd[i] / sqrt(1.0 - phis[i] * phis[i]);
+        for (int j = 0; j < W; ++j) chain[(size_t)j * D + i] = total * normal_next(&init);
+    }
+    normal_src run;
+    memset(&run, 0, sizeof run);
+    so_pcg64_seed(&run.eng, (uint64_t)(int64_t)run_number, 0);
+    for (int t = 1; t <= n_steps; ++t) {
+        const double* prev = chain + (size_t)(t - 1) * W * D;
+        double* next = chain + (size_t)t * W * D;
+        for (int j = 0; j < W * D; ++j) {
+            const int i = j % D;
+            next[j] = (offsets[i] + (phis[i] * prev[j])) + (sd[i] * normal_next(&run));
+        }
+    }
+    free(sd);
+    return 0;
+}
+
 int so_norm_autocov(int32_t dtype, void* chain, double avg, int32_t n)
 {
     if (!chain || n < 2 || (dtype != SO_F64 && dtype != SO_F32)) return -1;

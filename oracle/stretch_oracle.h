@@ -114,6 +114,11 @@ int so_norm_autocov(int32_t dtype, void* chain, double avg, int32_t n);
 int so_autocorr_times(int32_t dtype, const void* steps, int32_t n_steps, int32_t walkers, int32_t dims, int32_t window_scaling,
                       int32_t emulate_defect, void* out, void* functions /* NULL or [dims][n_steps]: the averaged functions */);
 
+/* The chain of the reference's AutoCorrCalc known-answer test (test/sequential/AcTime/src/main.cpp): AR(1) walkers moved
+ * by Mover::AutoRegressiveMove with libstdc++'s normal_distribution over pcg64.  chain: [n_steps + 1][W][D]. */
+int so_ar1_test_chain(int32_t run_number, int32_t W, int32_t D, int32_t n_steps, const double* offsets, const double* phis,
+                      const double* vars, double* chain);
+
 /* --- pcg64 (setseq_xsl_rr_128_64) primitives, exposed for known-answer tests ------------------- */
 typedef struct so_pcg64 {
     uint64_t state_hi, state_lo;

@@ -191,11 +191,21 @@ def make_autocorr(which=None):
         path = os.path.join(HERE, "autocov_series.npz")
         np.savez_compressed(path, **data)
         out.append(dict(name="autocov_series", bytes=os.path.getsize(path)))
-        for name in AUTOCORR_CLASS:  # one fresh process each
+        for name in ["actime_65535", "actime_262143"] + list(AUTOCORR_CLASS):  # one fresh process each
             import subprocess
             # MALLOC_MMAP_THRESHOLD_: glibc then serves every array above 64 KiB from fresh (zero) pages
             subprocess.check_call([sys.executable, os.path.abspath(__file__), "autocorr:" + name], env=dict(os.environ, MALLOC_MMAP_THRESHOLD_="65536"))
         return out
+    if which.startswith("actime_"):
+        # the reference's own known-answer test of AutoCorrCalc (test/sequential/AcTime/src/main.cpp) run by the reference:
+        # 100 walkers, run number 0, the five phi of the test; only the times and a digest of the chain are kept
+        n_steps = int(which.split("_")[1])
+        chain, times = po.reference_actime_test(n_steps)
+        assert np.all(np.isfinite(times)), "the reference's scratch memory was not zero: %r" % (times,)
+        path = os.path.join(HERE, which + ".npz")
+        np.savez_compressed(path, n_steps=n_steps, W=po.ACTIME_WALKERS, phis=np.array(po.ACTIME_PHIS), chain_sha256=sha(chain), times=times,
+                            recorded_in_the_test_source=np.array(po.ACTIME_RECORDED))
+        return [dict(name=which, times=times.tolist(), bytes=os.path.getsize(path))]
     n, W, D, seed, phi, scaling, dtype = AUTOCORR_CLASS[which]
     steps = ar_chain(n, W, D, seed, phi, po.np_dtype(dtype))
     times = po.reference_autocorr_times(steps, scaling, dtype)

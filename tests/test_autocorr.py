@@ -52,6 +52,25 @@ def test_oracle_autocov_against_the_live_reference(dtype):
         np.testing.assert_array_equal(po.norm_autocov(x, avg, dtype), po.reference_norm_autocov(x, avg, dtype))
 
 
+ANALYTIC = np.array([9.0, 20.0, 30.0, 60.0, 200.0])  # (1 + phi) / (1 - phi) of the test's five phi, as its source states
+
+
+@pytest.mark.parametrize("name", ["actime_65535", "actime_262143"])
+def test_oracle_reproduces_the_references_own_autocorr_test(name):
+    """test/sequential/AcTime/src/main.cpp, the reference's known-answer test of AutoCorrCalc, as the reference runs it
+    here (fixture): the oracle regenerates the chain (AutoRegressiveMove + libstdc++'s normal_distribution over pcg64,
+    digest pinned) and, emulating transferWalker's accumulation, reproduces the reference's five times bit for bit.
+    The numbers recorded in the test's source came from another build; they and the analytic values are met within
+    the estimator's scatter."""
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    chain = po.ar1_test_chain(int(z["n_steps"]), int(z["W"]), tuple(z["phis"]))
+    assert sha(chain) == str(z["chain_sha256"])
+    np.testing.assert_array_equal(po.autocorr_times(chain, 4, True), z["times"])
+    if name == "actime_262143":
+        np.testing.assert_allclose(z["times"], z["recorded_in_the_test_source"], rtol=0.015)
+        np.testing.assert_allclose(z["times"], ANALYTIC, rtol=0.03)
+
+
 def test_oracle_window_that_never_closes_returns_the_negated_sum():
     steps = ar_chain(64, 2, 1, 9, 0.99)  # 64 samples of a process with time ~200
     t = po.autocorr_times(steps, 1000)
@@ -76,6 +95,20 @@ def test_device_autocorr_matches_the_oracle_bit_for_bit(n, W, D, phi, window, dt
     got_t, got_f = capi.autocorr_times(steps, 0, window, want_functions=True)
     np.testing.assert_array_equal(got_f, want_f)
     np.testing.assert_array_equal(got_t, want_t)
+
+
+@pytest.mark.gpu
+def test_device_passes_the_references_own_autocorr_test():
+    """The reference's AcTime test (100 walkers x 5 AR(1) parameters x 262144 stored steps, 1 GB) on the device: bit
+    for bit the oracle's times (transforms of 2^18 points, in global memory), and the known answers of the test."""
+    z = np.load(os.path.join(GOLDEN_DIR, "actime_262143.npz"))
+    chain = po.ar1_test_chain(int(z["n_steps"]), int(z["W"]), tuple(z["phis"]))
+    assert sha(chain) == str(z["chain_sha256"])
+    got = capi.autocorr_times(chain, 0, 4)
+    np.testing.assert_array_equal(got, po.autocorr_times(chain, 4, False))
+    np.testing.assert_allclose(got, z["recorded_in_the_test_source"], rtol=0.01)  # 9.01951, 19.9437, 29.7831, 59.8488, 196.85
+    np.testing.assert_allclose(got, ANALYTIC, rtol=0.02)
+    np.testing.assert_allclose(got, z["times"], rtol=0.015)                       # the reference's run, defect and all
 
 
 @pytest.mark.gpu
@@ -113,7 +146,7 @@ def test_device_autocorr_steps_scattered_in_host_memory():
 
 @pytest.mark.gpu
 def test_device_autocorr_many_walkers_in_several_passes():
-    # 2100 walkers x 16 parameters x 4000 samples: more than one pass over the 256 MiB of functions
+    # 2100 walkers x 16 parameters x 4000 samples: more than one pass over the 1 GiB of functions
     n, W, D = 4000, 2100, 16
     steps = ar_chain(n, W, D, 3, np.linspace(0.2, 0.9, D))
     want = po.autocorr_times(steps, 4)
