@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 F64, F32 = 0, 1
 CALC_ISO_GAUSSIAN, CALC_DENSE_GAUSSIAN, CALC_ROSENBROCK, CALC_SKEWED_GAUSSIAN_2D = 0, 1, 2, 3
+MOVER_STRETCH, MOVER_DIFFERENTIAL_EVOLUTION = 0, 1
 MODE_SEQUENTIAL, MODE_COUNTER = 0, 1
 
 
@@ -27,7 +28,7 @@ def np_dtype(dtype):
 class _Config(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("num_walkers", C.c_int32), ("num_params", C.c_int32),
                 ("calc_id", C.c_int32), ("calc_params", C.c_void_p), ("calc_params_len", C.c_int32),
-                ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32), ("reserved", C.c_int32),
+                ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32), ("mover", C.c_int32),
                 ("seed", C.c_uint64), ("stream", C.c_uint64)]
 
 
@@ -140,12 +141,12 @@ def init_positions(dtype, W, D, salt=0):
 class Oracle:
     """The CPU restatement of EnsembleSampler + StretchMove."""
 
-    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, alpha=(2, 1)):
+    def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, alpha=(2, 1), mover=0):
         self.W, self.D, self.dtype = W, D, dtype
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self.cfg = _Config(dtype, W, D, calc_id, _ptr(self.params), 0 if self.params is None else self.params.size,
-                           alpha[0], alpha[1], 0, seed & (2**64 - 1), stream & (2**64 - 1))
+                           alpha[0], alpha[1], mover, seed & (2**64 - 1), stream & (2**64 - 1))
         self.h = C.c_void_p()
         rc = lib().so_create(C.byref(self.cfg), C.byref(self.h))
         if rc:
@@ -244,7 +245,7 @@ def ref_lib():
 def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_call, slicing=1, want_chain=True,
                   threads=0, dtype=F64, alpha_code=0):
     """Run MCMC::EnsembleSampler (threads=0) or ParallelEnsembleSampler (threads>=1) of the reference.
-    alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>.
+    alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>; 2: Mover::DifferentialEvolution.
 
     Returns dict(chain[(stored, W, D)] incl. step 0 = initial placement, accepted[n_calls], total[n_calls],
     stored, seconds, fraction)."""

@@ -23,6 +23,7 @@ using arrow_vendored::pcg64;
 
 #include "EnsembleSampler.h"
 #include "Movers/StretchMove.h"
+#include "Movers/DifferentialEvolution.h"
 #include "ParallelEnsembleSampler.h"
 #include "Common/SkewedGaussian.h"
 #include "Analysis/CovarianceMatrix.h"
@@ -33,14 +34,12 @@ using arrow_vendored::pcg64;
 
 namespace
 {
-template <class T, class Calc, class Dist>
-int runSequential(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
-                  int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
-                  unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
-                  double* seconds)
+template <class T, class MoverType>
+int runMover(MoverType& mover, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
+             int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+             unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
+             double* seconds)
 {
-    typedef MCMC::Mover::StretchMove<T, Calc, Dist> MoverType;
-    MoverType mover(D, seed, calc);
     MCMC::EnsembleSampler<T, MoverType> sampler(seed, W, D, mover);
     if (slicing > 1) sampler.setSlicingMode(true, slicing);
     sampler.setInitialWalkerPos(const_cast<T*>(initPos), const_cast<T*>(initLogp));
@@ -65,6 +64,31 @@ int runSequential(Calc& calc, int W, int D, int seed, const T* initPos, const T*
     return ok ? 0 : 1;
 }
 
+template <class T, class Calc, class Dist>
+int runSequential(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
+                  int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+                  unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
+                  double* seconds)
+{
+    typedef MCMC::Mover::StretchMove<T, Calc, Dist> MoverType;
+    MoverType mover(D, seed, calc);
+    return runMover<T, MoverType>(mover, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acceptedAfterCall,
+                                  totalAfterCall, storedSteps, seconds);
+}
+
+/* Mover::DifferentialEvolution (next row f3) through the same sequential sampler */
+template <class T, class Calc>
+int runDiffEvo(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
+               int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+               unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
+               double* seconds)
+{
+    typedef MCMC::Mover::DifferentialEvolution<T, Calc> MoverType;
+    MoverType mover(D, seed, calc);
+    return runMover<T, MoverType>(mover, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acceptedAfterCall,
+                                  totalAfterCall, storedSteps, seconds);
+}
+
 template <class T, class Calc>
 int runParallel(Calc& calc, int threads, int W, int D, int seed, const T* initPos, const T* initLogp, int nSteps,
                 double* seconds, double* acceptanceFraction)
@@ -87,6 +111,9 @@ int dispatch(int calcId, int threads, int alphaCode, int W, int D, const T* para
              unsigned long long* acc, unsigned long long* tot, int* stored, double* seconds, double* fraction)
 {
 #define MCMCPP_REF_GO(CALC)                                                                                        \
+    if (threads <= 0 && alphaCode == 2)                                                                            \
+        return runDiffEvo<T, decltype(CALC)>(CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing,   \
+                                             chainOut, chainCapacitySteps, acc, tot, stored, seconds);             \
     if (threads <= 0 && alphaCode == 1)                                                                            \
         return runSequential<T, decltype(CALC), MCMC::Utility::GwDistribution<T, 3, 2> >(                          \
             CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acc, \
@@ -175,7 +202,7 @@ extern "C"
 {
 /* threads <= 0: MCMC::EnsembleSampler; threads >= 1: MCMC::ParallelEnsembleSampler (timing only:
  * it is non-deterministic above one thread, ParallelEnsembleSampler.h:71-76).
- * alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>.
+ * alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>; 2: Mover::DifferentialEvolution.
  * dtype 0 = double, 1 = float.  chain_out holds up to chain_capacity_steps steps of W*D values
  * (chain step 0 is the initial placement, EnsembleSampler.h:228-229). */
 int ref_run(int dtype, int threads, int alpha_code, int W, int D, int calc_id, const void* params, int seed, const void* init_pos,

@@ -267,6 +267,7 @@ int so_run(so_sampler* s, int64_t n_saved, int32_t interval, void* chain_out,
     if (mode != SO_MODE_SEQUENTIAL && mode != SO_MODE_COUNTER) return -2;
     if (threads < 1) threads = 1;
     if (threads > 1 && mode != SO_MODE_COUNTER) return -3;
+    if (s->cfg.mover == SO_MOVER_DIFFERENTIAL_EVOLUTION && mode != SO_MODE_SEQUENTIAL) return -4;
     if (s->cfg.dtype == SO_F64)
         return run_f64(s, n_saved, interval, (double*)chain_out, accepted_per_step, mode, threads);
     return run_f32(s, n_saved, interval, (float*)chain_out, accepted_per_step, mode, threads);
@@ -276,6 +277,7 @@ int so_half_step_shard(so_sampler* s, int32_t color, int32_t begin, int32_t coun
 {
     if (!s || (color != 0 && color != 1)) return -1;
     if ((int)(s->half_steps & 1) != color) return -2; /* red, black, red, ... */
+    if (s->cfg.mover != SO_MOVER_STRETCH) return -4;
     if (begin < 0 || count < 0 || begin + count > s->cfg.num_walkers / 2) return -3;
     uint32_t a = s->cfg.dtype == SO_F64 ? half_step_shard_f64(s, color, begin, count)
                                         : half_step_shard_f32(s, color, begin, count);

@@ -49,6 +49,9 @@ enum {
     SO_MODE_COUNTER = 1     /* every walker jumps to draw 3*(h*n+i); embarrassingly parallel        */
 };
 
+#define SO_MOVER_STRETCH 0
+#define SO_MOVER_DIFFERENTIAL_EVOLUTION 1
+
 typedef struct so_config {
     int32_t dtype;       /* SO_F64 / SO_F32 */
     int32_t num_walkers; /* W, even, > 2*D (EnsembleSampler.h:207-208) */
@@ -58,7 +61,7 @@ typedef struct so_config {
     int32_t calc_params_len; /* number of elements in calc_params */
     int32_t gw_alpha_num;    /* stretch scale a = num/den of GwDistribution<T, num, den>; 0/0 = 2/1 */
     int32_t gw_alpha_den;
-    int32_t reserved;
+    int32_t mover;           /* SO_MOVER_*: 0 = StretchMove, 1 = DifferentialEvolution (sequential mode only) */
     uint64_t seed;   /* EnsembleSampler ctor randSeed (sign-extended int), MultiSampler.h:54 */
     uint64_t stream; /* 0 for EnsembleSampler (EnsembleSampler.h:217) */
 } so_config;

@@ -64,6 +64,19 @@ CASES = {
     "c2_16384x32": dict(W=16384, D=32, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=20, keep=[], rho=0.5,
                         digest=[1, 2, 20], sample_rows=[0, 1, 8191, 8192, 16383]),
     # BASELINE config 3 shape (Rosenbrock, D = 32) at a reduced walker count, digests only
+    # next row f3: Mover::DifferentialEvolution (alpha_code 2 selects it in the reference driver).  W/2 = 50, 40 and 7 are
+    # not powers of two (bounded_rand throw-aways) and 7 makes the second partner collide with the first every few updates
+    "de_iso64x4": dict(W=64, D=4, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=600, keep=[1, 2, 10, 600], mover=1, alpha_code=2),
+    "de_iso100x7": dict(W=100, D=7, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=300, keep=[1, 2, 10, 300], mover=1, alpha_code=2),
+    "de_iso14x3": dict(W=14, D=3, calc=po.CALC_ISO_GAUSSIAN, dtype=po.F64, steps=500, keep=[1, 2, 10, 500], mover=1, alpha_code=2),
+    "de_rosen80x8": dict(W=80, D=8, calc=po.CALC_ROSENBROCK, dtype=po.F64, steps=300, keep=[1, 2, 10, 300],
+                         params=[1.0, 100.0, 0.05], mover=1, alpha_code=2),
+    "de_dense96x16": dict(W=96, D=16, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=200, keep=[1, 2, 10, 200], rho=0.5, mover=1,
+                          alpha_code=2),
+    "de_dense80x5_f32": dict(W=80, D=5, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F32, steps=300, keep=[1, 2, 10, 300], rho=0.3, mover=1,
+                             alpha_code=2),
+    "de_c2_16384x32": dict(W=16384, D=32, calc=po.CALC_DENSE_GAUSSIAN, dtype=po.F64, steps=10, keep=[], rho=0.5, mover=1, alpha_code=2,
+                           digest=[1, 2, 10], sample_rows=[0, 1, 8191, 8192, 16383]),
     "c3_4096x32": dict(W=4096, D=32, calc=po.CALC_ROSENBROCK, dtype=po.F64, steps=20, keep=[],
                        params=[1.0, 100.0, 0.05], digest=[1, 2, 20], sample_rows=[0, 2047, 2048, 4095]),
 }
@@ -79,7 +92,7 @@ def make(name, c):
     else:
         params = None
     alpha = c.get("alpha", (2, 1))
-    orc = po.Oracle(W, D, c["calc"], params, seed=0, dtype=dtype, alpha=alpha)
+    orc = po.Oracle(W, D, c["calc"], params, seed=0, dtype=dtype, alpha=alpha, mover=c.get("mover", 0))
     if c.get("skewed_init"):
         pos, logp = po.reference_skewed_initial_values(W, 0.13, 53)
     else:
@@ -94,7 +107,7 @@ def make(name, c):
     # reference totals count the initial placement as one accepted step per walker (Walker.h:76,168)
     acc_per_call = np.diff(np.concatenate([[W], acc_cum])).astype(np.uint32)
     out = dict(W=np.int32(W), D=np.int32(D), calc=np.int32(c["calc"]), dtype=np.int32(dtype), seed=np.int64(0),
-               slicing=np.int32(slicing), steps=np.int32(steps), alpha=np.asarray(alpha, dtype=np.int32),
+               slicing=np.int32(slicing), steps=np.int32(steps), alpha=np.asarray(alpha, dtype=np.int32), mover=np.int32(c.get("mover", 0)),
                params=(np.zeros(0, dtype=t) if params is None else params),
                accepted_per_call=acc_per_call, accepted_total=np.uint64(acc_cum[-1]),
                total_steps=np.uint64(ref["total"][-1]))

@@ -12,6 +12,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SMALL = ["iso64x4", "iso64x4_alpha3_2", "iso100x7", "iso64x4_f32", "dense96x16", "dense80x5_f32", "rosen80x8", "rosen200x33",
          "skewed320x2"]
 DIGEST = ["iso600x130", "c2_16384x32", "c3_4096x32"]
+# next row f3: Mover::DifferentialEvolution
+DE_SMALL = ["de_iso64x4", "de_iso100x7", "de_iso14x3", "de_rosen80x8", "de_dense96x16", "de_dense80x5_f32"]
+DE_DIGEST = ["de_c2_16384x32"]
 
 
 def sha(a):
@@ -28,6 +31,7 @@ class Golden:
         self.seed, self.slicing, self.steps = int(z["seed"]), int(z["slicing"]), int(z["steps"])
         self.params = z["params"] if z["params"].size else None
         self.alpha = tuple(int(v) for v in z["alpha"]) if "alpha" in z.files else (2, 1)
+        self.mover = int(z["mover"]) if "mover" in z.files else 0
         self.accepted_per_call = z["accepted_per_call"]
         self.accepted_total = int(z["accepted_total"])  # includes the W initial placements
         self.total_steps = int(z["total_steps"])
