@@ -88,8 +88,17 @@ typedef struct mcmcpp_hip_config {
     void* hip_stream;        /* hipStream_t to launch on when MCMCPP_HIP_FLAG_CALLER_STREAM is set (NULL is then the
                                 legacy default stream); otherwise ignored and the handle owns a private stream */
     uint32_t flags;          /* MCMCPP_HIP_FLAG_* */
-    uint32_t reserved;
+    uint32_t mover;          /* MCMCPP_HIP_MOVER_*: which Mover::updateWalker the kernels implement; 0 = StretchMove */
 } mcmcpp_hip_config;
+
+/* Movers (reference MCMCpp/Movers/).  DIFFERENTIAL_EVOLUTION = Mover::DifferentialEvolution
+ * (Movers/DifferentialEvolution.h:80-112) with the gamma and jitter bounds its constructors set -- the samplers work on
+ * a copy of the user's mover whose copy constructor re-initialises both, so overrideGamma / overrideRandBounds never
+ * reach a sampler in the reference either.  Same stream, same draws, same chain as the reference, bit for bit
+ * (tests/test_diffevo.py); one whole ensemble per handle: run / set_state / get_state / counters / calc_logp are
+ * supported, seek, shards and half_step_async are not (the stream position depends on the draws thrown away so far). */
+#define MCMCPP_HIP_MOVER_STRETCH 0u
+#define MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION 1u
 
 /* launch every kernel and copy on the caller's stream (config.hip_stream), so that the caller's own work on
  * that stream -- e.g. RCCL collectives issued through torch.distributed -- is ordered with the half-steps */

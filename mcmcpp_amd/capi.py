@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 F64, F32 = 0, 1
 CALC_ISO_GAUSSIAN, CALC_DENSE_GAUSSIAN, CALC_ROSENBROCK, CALC_SKEWED_GAUSSIAN_2D = 0, 1, 2, 3
+MOVER_STRETCH, MOVER_DIFFERENTIAL_EVOLUTION = 0, 1
 OK = 0
 
 # every symbol include/mcmcpp_hip.h declares
@@ -32,7 +33,7 @@ class Config(C.Structure):
                 ("shard_begin", C.c_int32), ("shard_count", C.c_int32), ("graph_steps", C.c_int32),
                 ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32),
                 ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p), ("flags", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("mover", C.c_uint32)]
 
 FLAG_CALLER_STREAM = 1
 
@@ -120,14 +121,14 @@ class HipSampler:
     """Thin owner of one mcmcpp_hip_sampler handle (one GPU)."""
 
     def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, device=-1, shard_begin=0,
-                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1)):
+                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1), mover=0):
         self.W, self.D, self.dtype = W, D, dtype
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self.cfg = Config(C.sizeof(Config), dtype, W, D, calc_id, 0 if self.params is None else self.params.size,
                           _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
                           shard_count, graph_steps, alpha[0], alpha[1], device_positions,
-                          0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, 0)
+                          0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, mover)
         self.h = C.c_void_p()
         rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
         if rc != OK:

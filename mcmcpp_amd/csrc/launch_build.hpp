@@ -63,6 +63,13 @@ void launch_calc(const T* pos, T* out, const T* prm, long long count, int dims, 
                        count, dims, vec_ok);
 }
 
+template <class T, class Calc, int EPL, int LPW>
+void launch_de(const DeArgs<T>& a, unsigned grid, hipStream_t st)
+{
+    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
+    hipLaunchKernelGGL((de_update_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a);
+}
+
 template <class T, class Calc, int LPWLOG, int EPLSHIFT>
 void put(LaunchTable<T>& t)
 {
@@ -76,6 +83,7 @@ void put(LaunchTable<T>& t)
         t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+    t.de_update[LPWLOG][EPLSHIFT] = &launch_de<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
 }
 
 // OnlyLpw1: only the single-lane mapping is meaningful (a fixed low-dimensional target such as D = 2)

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "diffevo_kernel.hpp"
 #include "full_step_kernel.hpp"
 #include "stretch_kernel.hpp"
 
@@ -13,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430009u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D43000Au;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -32,6 +33,9 @@ struct LaunchTable
     // (generic) or 32 per colour (matrix-core variant)
     HalfStepFn full_step[kLpwLevels][kMaxEplShift];
     HalfStepFn full_step_mc[kLpwLevels][kMaxEplShift];
+    // Mover::DifferentialEvolution (diffevo_kernel.hpp): one launch updates a whole half
+    typedef void (*DeFn)(const DeArgs<T>&, unsigned grid, hipStream_t);
+    DeFn de_update[kLpwLevels][kMaxEplShift];
 };
 
 // red_base != nullptr: black records, with partner2 (see DrawRec)

@@ -26,6 +26,7 @@
 #include "../../include/mcmcpp_hip.h"
 #define MCMCPP_DEFINE_REDUCE_KERNEL
 #include "launch_table.hpp"
+#include "sampler_base.hpp"
 
 using namespace mcmcpp;
 
@@ -140,6 +141,10 @@ const LaunchTable<float>* table_for<float>(int calc_id)
 
 namespace mcmcpp
 {
+const void* launch_table_lookup(int dtype, int calc_id)
+{
+    return dtype == MCMCPP_HIP_F64 ? static_cast<const void*>(table_for<double>(calc_id)) : static_cast<const void*>(table_for<float>(calc_id));
+}
 void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, const U128* red_base, hipStream_t stream)
 {
     const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
@@ -157,45 +162,6 @@ void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int par
                        partial_waves, count, ctl_after, run);
 }
 }  // namespace mcmcpp
-
-// ---------------------------------------------------------------------------------------------------
-struct mcmcpp_hip_sampler
-{
-    std::string error;
-    virtual ~mcmcpp_hip_sampler() {}
-    virtual int set_state(const void* pos, const void* logp) = 0;
-    virtual int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) = 0;
-    virtual int get_state(void* pos, void* logp, uint32_t* n_accept) = 0;
-    virtual int reset_counters() = 0;
-    virtual int seek(uint64_t steps_done) = 0;
-    virtual int get_counters(uint64_t* accepted, uint64_t* steps, uint64_t* ties, uint64_t* redraws) = 0;
-    virtual int calc_logp(const void* pos, int64_t count, void* out) = 0;
-    virtual int last_run_timing(double* ms, int64_t* launches) = 0;
-    virtual int half_step_async(int32_t color, int64_t save_slot) = 0;
-    virtual int bind_device_chain(void* chain, int64_t slots) = 0;
-    virtual void* device_positions() = 0;
-    virtual int shard_span(int32_t color, int64_t* off, int64_t* cnt) = 0;
-    virtual int synchronize() = 0;
-    virtual int debug_stamps(unsigned long long* out8) = 0;
-
-    int fail(int code, const char* fmt, ...)
-    {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        error = buf;
-        return code;
-    }
-};
-
-#define HIP_TRY(expr)                                                                                       \
-    do                                                                                                      \
-    {                                                                                                       \
-        hipError_t e_ = (expr);                                                                             \
-        if (e_ != hipSuccess) return fail(MCMCPP_HIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
 
 namespace
 {
@@ -1253,6 +1219,9 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
     }
     }
     if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
+    if (c->mover != MCMCPP_HIP_MOVER_STRETCH && c->mover != MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION) BAD("unknown mover %u", c->mover);
+    if (c->mover == MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION && (c->shard_count != 0 || c->device_positions))
+        BAD("the differential-evolution mover runs one whole ensemble per handle (no shards, no caller-owned position buffer)");
     if (c->gw_alpha_num < 0 || c->gw_alpha_den < 0 || ((c->gw_alpha_num == 0) != (c->gw_alpha_den == 0)))
         BAD("gw_alpha_num/gw_alpha_den must both be positive (or both 0 for the default 2/1)");
     if (c->gw_alpha_num > 0 && c->gw_alpha_num <= c->gw_alpha_den) BAD("the stretch scale alpha must exceed 1");
@@ -1310,7 +1279,12 @@ int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out)
     if (rc) return rc;
     mcmcpp_hip_sampler* h = nullptr;
     int irc;
-    if (cfg->dtype == MCMCPP_HIP_F64)
+    if (cfg->mover == MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION)
+    {
+        h = mcmcpp::make_de_sampler(*cfg, &irc);
+        if (!h) return MCMCPP_HIP_E_NOMEM;
+    }
+    else if (cfg->dtype == MCMCPP_HIP_F64)
     {
         Sampler<double>* s = new (std::nothrow) Sampler<double>();
         if (!s) return MCMCPP_HIP_E_NOMEM;

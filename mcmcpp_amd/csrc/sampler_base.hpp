@@ -1,0 +1,58 @@
+// sampler_base.hpp -- what the C ABI handle is behind include/mcmcpp_hip.h: one abstract interface, implemented by the
+// stretch-move sampler (mcmcpp_hip.hip) and by the differential-evolution sampler (diffevo.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mcmcpp_hip.h"
+
+struct mcmcpp_hip_sampler
+{
+    std::string error;
+    virtual ~mcmcpp_hip_sampler() {}
+    virtual int set_state(const void* pos, const void* logp) = 0;
+    virtual int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) = 0;
+    virtual int get_state(void* pos, void* logp, uint32_t* n_accept) = 0;
+    virtual int reset_counters() = 0;
+    virtual int seek(uint64_t steps_done) = 0;
+    virtual int get_counters(uint64_t* accepted, uint64_t* steps, uint64_t* ties, uint64_t* redraws) = 0;
+    virtual int calc_logp(const void* pos, int64_t count, void* out) = 0;
+    virtual int last_run_timing(double* ms, int64_t* launches) = 0;
+    virtual int half_step_async(int32_t color, int64_t save_slot) = 0;
+    virtual int bind_device_chain(void* chain, int64_t slots) = 0;
+    virtual void* device_positions() = 0;
+    virtual int shard_span(int32_t color, int64_t* off, int64_t* cnt) = 0;
+    virtual int synchronize() = 0;
+    virtual int debug_stamps(unsigned long long* out8) = 0;
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(expr)                                                                                       \
+    do                                                                                                      \
+    {                                                                                                       \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return fail(MCMCPP_HIP_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+
+namespace mcmcpp
+{
+// launch table (LaunchTable<double> / LaunchTable<float>) of a built-in or registered calculator, or nullptr
+const void* launch_table_lookup(int dtype, int calc_id);
+// Mover::DifferentialEvolution (diffevo.hip); *rc receives the init result, the handle carries the message
+mcmcpp_hip_sampler* make_de_sampler(const mcmcpp_hip_config& cfg, int* rc);
+}  // namespace mcmcpp

@@ -63,3 +63,98 @@ def test_oracle_differential_evolution_against_the_live_reference():
     ref = po.reference_run(W, D, po.CALC_ISO_GAUSSIAN, None, 9, pos, lp, 1, 250, alpha_code=2)
     np.testing.assert_array_equal(ref["chain"][1:], chain)
     assert int(acc.sum()) + W == int(ref["accepted"][0])
+
+
+# ---- the device path (mcmcpp_amd/csrc/diffevo.hip, diffevo_kernel.hpp) through the C ABI ---------------------------------
+from mcmcpp_amd import capi  # noqa: E402
+
+
+def run_device(g, split=None):
+    s = capi.HipSampler(g.W, g.D, g.calc, g.params, seed=g.seed, dtype=g.dtype, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    np.testing.assert_array_equal(s.calc_logp(g.init_pos), g.init_logp)
+    s.set_state(g.init_pos, g.init_logp)
+    done, acc_calls = 0, []
+    for k in sorted(set(g.checked_steps + [g.steps] + (split or []))):
+        chain, acc = s.run(k - done, g.slicing)
+        acc_calls.append(acc.reshape(k - done, g.slicing).sum(axis=1))
+        done = k
+        if k in g.checked_steps:
+            g.check_chain_step(k, chain[-1])
+    np.testing.assert_array_equal(np.concatenate(acc_calls), g.accepted_per_call)
+    pos, logp, nacc = s.get_state()
+    assert int(nacc.sum()) + g.W == g.accepted_total
+    c = s.counters()
+    assert c["near_ties"] == 0
+    return s, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DE_SMALL + DE_DIGEST)
+def test_device_differential_evolution_matches_reference_golden(name):
+    g = Golden(name)
+    s, c = run_device(g)
+    orc = run_oracle(g)
+    assert c["redraws"] == orc.redraws  # every draw thrown away was followed
+
+
+@pytest.mark.gpu
+def test_device_differential_evolution_resumes_across_calls():
+    run_device(Golden("de_iso14x3"), split=[3, 77, 78, 200])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("W,D,calc,params,dt,steps,interval", [
+    (8, 1, po.CALC_ISO_GAUSSIAN, None, po.F64, 300, 1), (10, 2, po.CALC_ISO_GAUSSIAN, None, po.F64, 200, 3),
+    (40, 3, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 150, 1), (70, 33, po.CALC_ISO_GAUSSIAN, None, po.F64, 60, 2),
+    (140, 64, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 40, 1), (300, 130, po.CALC_ISO_GAUSSIAN, None, po.F64, 20, 1),
+    (600, 257, po.CALC_ISO_GAUSSIAN, None, po.F64, 8, 1), (1026, 32, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 40, 1),
+    (64, 7, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F32, 200, 1), (4096, 16, po.CALC_ISO_GAUSSIAN, None, po.F32, 20, 5),
+    (4100, 8, po.CALC_ISO_GAUSSIAN, None, po.F64, 30, 1),
+])
+def test_device_differential_evolution_matches_the_oracle(W, D, calc, params, dt, steps, interval):
+    pos = po.init_positions(dt, W, D, salt=6)
+    orc = po.Oracle(W, D, calc, params, seed=21, dtype=dt, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
+    lp = orc.logp(pos)
+    orc.set_state(pos, lp)
+    want_chain, want_acc = orc.run(steps, interval)
+    s = capi.HipSampler(W, D, calc, params, seed=21, dtype=dt, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    s.set_state(pos, lp)
+    chain, acc = s.run(steps, interval)
+    np.testing.assert_array_equal(chain, want_chain)
+    np.testing.assert_array_equal(acc, want_acc)
+    for got, want in zip(s.get_state(), orc.get_state()):
+        np.testing.assert_array_equal(got, want)
+    c = s.counters()
+    assert c["redraws"] == orc.redraws and c["ensemble_steps"] == steps * interval
+    if dt == po.F64:  # (fp32 decisions within a few ulp of flipping do occur at this count; chain equality above is the test)
+        assert c["near_ties"] == 0 and orc.near_ties == 0
+
+
+@pytest.mark.gpu
+def test_device_differential_evolution_dense_c2_shape_statistics():
+    # BASELINE's C2 target under the other mover: same stationary distribution (variance 1 per parameter for the AR(1) covariance)
+    from tests.golden.make_golden import ar1_precision
+    W, D = 4096, 32
+    P = ar1_precision(D, 0.5, np.float64)
+    pos = po.init_positions(po.F64, W, D, salt=0)
+    s = capi.HipSampler(W, D, capi.CALC_DENSE_GAUSSIAN, P.ravel(), seed=1, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    s.set_state(pos, s.calc_logp(pos))
+    s.run(1, 600, save_chain=False)
+    chain, acc = s.run(10, 20)
+    var = chain.reshape(-1, D).var(axis=0)
+    assert np.all(np.abs(var - 1.0) < 0.08), var
+    rate = acc.sum() / (W * acc.size)
+    assert 0.2 < rate < 0.6, rate
+
+
+@pytest.mark.gpu
+def test_device_differential_evolution_refuses_what_it_cannot_do():
+    s = capi.HipSampler(64, 4, capi.CALC_ISO_GAUSSIAN, None, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    pos = po.init_positions(po.F64, 64, 4)
+    s.set_state(pos, s.calc_logp(pos))
+    with pytest.raises(capi.HipError):
+        s.seek(10)
+    with pytest.raises(capi.HipError):
+        capi.HipSampler(64, 4, capi.CALC_ISO_GAUSSIAN, None, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION, shard_begin=0, shard_count=8)
+    with pytest.raises(capi.HipError):
+        capi.HipSampler(64, 4, capi.CALC_ISO_GAUSSIAN, None, mover=7)
