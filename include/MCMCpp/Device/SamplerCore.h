@@ -38,7 +38,7 @@ public:
     typedef Chain::ChainPsetIterator<ParamType> PsetItt;
     typedef Chain::ChainStepIterator<ParamType> StepItt;
 
-    static_assert(Mover::RunsOnDevice, "the MI355X samplers run movers that exist as device kernels: MCMC::Mover::StretchMove");
+    static_assert(Mover::RunsOnDevice, "the MI355X samplers run movers that exist as device kernels: MCMC::Mover::StretchMove, MCMC::Mover::DifferentialEvolution");
     static_assert(Utility::CheckPerformAction<PostStepAction, void, const StepItt&, const StepItt&>::value,
                   "the PostStepAction needs 'void performAction(const StepItt& start, const StepItt& end)'");
 
@@ -63,6 +63,7 @@ public:
         cfg.device = -1;
         cfg.gw_alpha_num = Mover::DistributionType::Numerator;
         cfg.gw_alpha_den = Mover::DistributionType::Denominator;
+        cfg.mover = Mover::HipMoverId;
         device.create(cfg);
     }
 

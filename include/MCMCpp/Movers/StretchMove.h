@@ -42,6 +42,7 @@ public:
     typedef CustomDistribution DistributionType;
     /// Marks the movers the MI355X samplers can run.
     static const bool RunsOnDevice = true;
+    static const unsigned HipMoverId = 0u;  // MCMCPP_HIP_MOVER_STRETCH
 
     static_assert(Utility::CheckCalcLogPostProb<Calculator, ParamType, ParamType*>::value,
                   "StretchMove: the Calculator needs 'ParamType calcLogPostProb(ParamType* paramSet)'");

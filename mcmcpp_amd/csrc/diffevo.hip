@@ -1,7 +1,7 @@
 // diffevo.hip -- host side and stream-planning kernels of Mover::DifferentialEvolution on gfx950 (SURVEY.md 8f row f3;
 // reference MCMCpp/Movers/DifferentialEvolution.h:80-112 inside EnsembleSampler::performStep, EnsembleSampler.h:342-354).
-// See diffevo_kernel.hpp for the scheme: plan (parallel) -> resolve (a few dozen sequential steps) -> update (parallel),
-// three launches per half-step on one stream, the stream position and the error flag travelling in device memory.
+// See diffevo_kernel.hpp for the scheme: plan (parallel) -> update (a few dozen sequential steps from LDS, then parallel),
+// two launches per half-step on one stream, the stream position and the error flag travelling in device memory.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -18,120 +18,72 @@ using namespace mcmcpp;
 
 namespace
 {
-// Walker k of the half: would an update that starts r draws late (r = 0..kDeMaxShift) throw draws away?  Streams over
-// the kDeRaw raw draws behind (D+3)k once; the rare walker for which the answer is yes for some r writes them out and
-// builds its table extra[r] from them.
+// Would an update of walker k that starts r draws late (r = 0..kDeMaxShift) throw draws away?  One wavefront per walker:
+// lane j makes raw draw j behind (D+3)k (one table jump from the walker's base state), neighbouring lanes compare, and
+// for the rare walker where the answer is yes for some r, lane r walks the update that starts at draw r and the table
+// extra[r] goes to the candidate list.
 __global__ void __launch_bounds__(256)
-de_plan_kernel(DeCtl* ctl, DeCand* cand, uint64_t* raw_scratch, const Affine128* jump_hi, const Affine128* jump_lo, U128 inc, uint64_t threshold, int n)
+de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine128* jump_lo, const Affine128* jump_small, U128 inc, uint64_t threshold, int n)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n) return;
+    __shared__ uint64_t sh_raw[4][64];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const bool pow2 = (n & (n - 1)) == 0;
-    const U128 s0 = apply(jump_lo[k & 255], apply(jump_hi[k >> 8], ctl->state));
-    // clean(j): draws j and j+1 are both kept and name different walkers, i.e. an update starting at j throws nothing away
-    U128 s = pcg_step(s0, inc);
-    uint64_t prev = pcg_output(s);
-    bool dirty = false;
-    for (int j = 0; j <= kDeMaxShift; ++j)
+    const U128 state = ctl->state;
+    const Affine128 j_draw = jump_small[(lane < kDeRaw ? lane : kDeRaw - 1) + 1];
+    const int waves = gridDim.x * 4;
+    (void)inc;
+    for (int k = blockIdx.x * 4 + wib; k < n; k += waves)
     {
-        s = pcg_step(s, inc);
-        const uint64_t cur = pcg_output(s);
-        dirty = dirty || prev < threshold || cur < threshold || de_bounded(prev, n, pow2) == de_bounded(cur, n, pow2);
-        prev = cur;
-    }
-    if (!dirty) return;
-    const uint32_t slot = atomicAdd(&ctl->cand_count, 1u);
-    if (slot >= (uint32_t)kDeMaxCand)
-    {
-        atomicOr(&ctl->error, kDeErrCand);
-        return;
-    }
-    uint64_t* raw = raw_scratch + (size_t)slot * kDeRaw;
-    s = s0;
-    for (int j = 0; j < kDeRaw; ++j)
-    {
-        s = pcg_step(s, inc);
-        raw[j] = pcg_output(s);
-    }
-    DeCand c;
-    c.k = (uint32_t)k;
-    for (int r = 0; r <= kDeMaxShift; ++r)
-    {
-        // DifferentialEvolution.h:83-87 from draw r on
-        int at = r;
-        const int end = r + kDeWindow;
-        uint64_t v;
-        do v = raw[at++];
-        while (v < threshold && at < end);
-        const uint32_t ind1 = de_bounded(v, n, pow2);
-        uint32_t ind2 = ind1;
-        bool overrun = v < threshold;
-        do
+        const U128 base = apply(jump_lo[k & 255], apply(jump_hi[k >> 8], state));
+        const uint64_t raw = pcg_output(apply(j_draw, base));
+        const uint64_t nxt = __shfl_down(raw, 1);
+        // clean(j): draws j and j+1 are both kept and name different walkers: an update starting at j throws nothing away
+        const bool bad = lane <= kDeMaxShift && (raw < threshold || nxt < threshold || de_bounded(raw, n, pow2) == de_bounded(nxt, n, pow2));
+        if (__ballot(bad) == 0) continue;
+        uint32_t slot = 0;
+        if (lane == 0) slot = atomicAdd(&ctl->cand_count, 1u);
+        slot = __shfl(slot, 0);
+        if (slot >= (uint32_t)kDeMaxCand)
         {
-            if (at >= end)
-            {
-                overrun = true;
-                break;
-            }
-            do v = raw[at++];
+            if (lane == 0) atomicOr(&ctl->error, kDeErrCand);
+            continue;
+        }
+        // (one wavefront: its LDS accesses execute in order; the fences keep the compiler from moving them)
+        sh_raw[wib][lane] = raw;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane <= kDeMaxShift)
+        {
+            // DifferentialEvolution.h:83-87 from draw `lane` on
+            const uint64_t* rw = sh_raw[wib];
+            int at = lane;
+            const int end = lane + kDeWindow;
+            uint64_t v;
+            do v = rw[at++];
             while (v < threshold && at < end);
-            if (v < threshold) overrun = true;
-            ind2 = de_bounded(v, n, pow2);
-        } while (ind2 == ind1);
-        c.extra[r] = overrun ? (uint8_t)kDeOverrun : (uint8_t)(at - r - 2);  // (an error only if the walk below comes through r)
-    }
-    cand[slot] = c;
-}
-
-// One workgroup: sort the candidates by walker, walk them in order (the sequential part of the whole scheme), leave the
-// resolved list for the update kernel and the stream position for the next half-step.
-__global__ void __launch_bounds__(256)
-de_resolve_kernel(DeCtl* ctl, DeCtl* ctl_next, const DeCand* cand, DePlan* plan, Affine128 half_jump, const Affine128* jump_small)
-{
-    __shared__ uint32_t sh_k[kDeMaxCand];
-    __shared__ uint16_t sh_order[kDeMaxCand];
-    const int c = (int)(ctl->cand_count < (uint32_t)kDeMaxCand ? ctl->cand_count : (uint32_t)kDeMaxCand);
-    for (int j = threadIdx.x; j < c; j += 256) sh_k[j] = cand[j].k;
-    __syncthreads();
-    for (int j = threadIdx.x; j < c; j += 256)
-    {
-        int rank = 0;
-        const uint32_t mine = sh_k[j];
-        for (int i = 0; i < c; ++i) rank += sh_k[i] < mine ? 1 : 0;  // (walker indices are distinct)
-        sh_order[rank] = (uint16_t)j;
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    int r = 0;
-    uint32_t err = ctl->error;
-    for (int j = 0; j < c; ++j)
-    {
-        const DeCand& cd = cand[sh_order[j]];
-        int own = cd.extra[r <= kDeMaxShift ? r : kDeMaxShift];
-        if (own == kDeOverrun)
-        {
-            err |= kDeErrWindow;
-            own = 0;
+            const uint32_t ind1 = de_bounded(v, n, pow2);
+            uint32_t ind2 = ind1;
+            bool overrun = v < threshold;
+            do
+            {
+                if (at >= end)
+                {
+                    overrun = true;
+                    break;
+                }
+                do v = rw[at++];
+                while (v < threshold && at < end);
+                if (v < threshold) overrun = true;
+                ind2 = de_bounded(v, n, pow2);
+            } while (ind2 == ind1);
+            // (an overrun is an error only if the walk in the update kernel comes through this start)
+            cand[slot].extra[lane] = overrun ? (uint8_t)kDeOverrun : (uint8_t)(at - lane - 2);
         }
-        r += own;
-        if (r > kDeMaxShift)
-        {
-            err |= kDeErrShift;
-            r = kDeMaxShift;
-        }
-        DePlan p;
-        p.k = cd.k;
-        p.shift_after = (uint16_t)r;
-        p.own = (uint16_t)own;
-        plan[j] = p;
+        if (lane == 0) cand[slot].k = (uint32_t)k;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    ctl->plan_count = (uint32_t)c;
-    ctl->cand_count = 0;
-    ctl->error = err;
-    ctl_next->state = apply(jump_small[r], apply(half_jump, ctl->state));
-    ctl_next->extra_total = ctl->extra_total + (unsigned long long)r;
-    ctl_next->error = err;
-    ctl_next->cand_count = 0;
 }
 
 int pow2_at_least(int v)
@@ -206,8 +158,6 @@ public:
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
         HIP_TRY(hipMalloc(&d_ctl, sizeof(DeCtl) * 2));
         HIP_TRY(hipMalloc(&d_cand, sizeof(DeCand) * kDeMaxCand));
-        HIP_TRY(hipMalloc(&d_plan, sizeof(DePlan) * kDeMaxCand));
-        HIP_TRY(hipMalloc(&d_raw, sizeof(uint64_t) * (size_t)kDeMaxCand * kDeRaw));
         HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
         if (c.calc_params_len > 0)
@@ -297,7 +247,7 @@ public:
                 chain_bytes = (size_t)piece * step_bytes;
             }
         }
-        const int64_t acc_piece = accepted_per_step ? piece * (int64_t)interval : 0;
+        const int64_t acc_piece = accepted_per_step ? piece * (int64_t)interval * kDeAccSlots : 0;
         if (accepted_per_step && (size_t)acc_piece > acc_count)
         {
             if (d_acc) HIP_TRY(hipFree(d_acc));
@@ -312,7 +262,8 @@ public:
         a.logp = d_logp;
         a.n_accept = d_nacc;
         a.calc_params = d_params;
-        a.plan = d_plan;
+        a.cand = d_cand;
+        a.half_jump = half_jump;
         a.jump_hi = d_jump_hi;
         a.jump_lo = d_jump_lo;
         a.jump_small = d_jump_small;
@@ -327,13 +278,14 @@ public:
         a.n = n;
         a.dims = D;
         a.vec_ok = vec_ok;
-        const unsigned plan_grid = (unsigned)((n + 255) / 256);
+        // a wavefront per walker, at most 8 wavefronts per SIMD's worth of workgroups
+        const unsigned plan_grid = (unsigned)(n / 4 < 2048 ? (n + 3) / 4 : 2048);
         const int per_block = (64 / lpw) * kWavesPerBlock;
         const unsigned update_grid = (unsigned)((n + per_block - 1) / per_block);
         for (int64_t first = 0; first < n_saved; first += piece)
         {
             const int64_t now = n_saved - first < piece ? n_saved - first : piece;
-            if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)(now * interval), stream));
+            if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)(now * interval) * kDeAccSlots, stream));
             for (int64_t s = 0; s < now; ++s)
                 for (int32_t j = 0; j < interval; ++j)
                 {
@@ -342,23 +294,33 @@ public:
                     {
                         DeCtl* cur = d_ctl + (half_steps & 1);
                         DeCtl* nxt = d_ctl + ((half_steps + 1) & 1);
-                        hipLaunchKernelGGL(de_plan_kernel, dim3(plan_grid), dim3(256), 0, stream, cur, d_cand, d_raw, d_jump_hi, d_jump_lo, inc, threshold, n);
-                        hipLaunchKernelGGL(de_resolve_kernel, dim3(1), dim3(256), 0, stream, cur, nxt, d_cand, d_plan, half_jump, d_jump_small);
+                        hipLaunchKernelGGL(de_plan_kernel, dim3(plan_grid), dim3(256), 0, stream, cur, d_cand, d_jump_hi, d_jump_lo, d_jump_small, inc, threshold, n);
                         a.ctl = cur;
+                        a.ctl_next = nxt;
                         a.color = color;
                         a.save_slot = save ? (long long)s : -1;
-                        a.accepted = accepted_per_step ? d_acc + (s * interval + j) : nullptr;
+                        a.accepted = accepted_per_step ? d_acc + (s * interval + j) * kDeAccSlots : nullptr;
                         update_fn(a, update_grid, stream);
                         ++half_steps;
-                        last_launches += 3;
+                        last_launches += 2;
                     }
                 }
             HIP_TRY(hipGetLastError());
             if (chain_out)
                 HIP_TRY(hipMemcpyAsync(static_cast<char*>(chain_out) + (size_t)first * step_bytes, d_chain, (size_t)now * step_bytes, hipMemcpyDeviceToHost, stream));
             if (accepted_per_step)
-                HIP_TRY(hipMemcpyAsync(accepted_per_step + first * interval, d_acc, sizeof(uint32_t) * (size_t)(now * interval), hipMemcpyDeviceToHost, stream));
+            {
+                acc_host.resize((size_t)(now * interval) * kDeAccSlots);
+                HIP_TRY(hipMemcpyAsync(acc_host.data(), d_acc, sizeof(uint32_t) * acc_host.size(), hipMemcpyDeviceToHost, stream));
+            }
             HIP_TRY(hipStreamSynchronize(stream));
+            if (accepted_per_step)
+                for (int64_t e = 0; e < now * interval; ++e)
+                {
+                    uint32_t sum = 0;
+                    for (int q = 0; q < kDeAccSlots; ++q) sum += acc_host[(size_t)e * kDeAccSlots + q];
+                    accepted_per_step[first * interval + e] = sum;
+                }
         }
         steps_since_reset += (uint64_t)total;
         DeCtl c;
@@ -476,7 +438,7 @@ private:
     {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_cand, d_plan, d_raw, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc};
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_cand, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -493,10 +455,9 @@ private:
     Diag* d_diag = nullptr;
     DeCtl* d_ctl = nullptr;
     DeCand* d_cand = nullptr;
-    DePlan* d_plan = nullptr;
-    uint64_t* d_raw = nullptr;
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_jump_small = nullptr;
     size_t chain_bytes = 0, acc_count = 0;
+    std::vector<uint32_t> acc_host;
     U128 state0, inc;
     Affine128 half_jump;
     uint64_t threshold = 0, half_steps = 0, steps_since_reset = 0;

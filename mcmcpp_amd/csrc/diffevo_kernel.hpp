@@ -6,14 +6,15 @@
 // next walker's first draw follows this walker's last, so a walker's place in the stream depends on how many draws
 // all walkers before it threw away -- the reason the reference's loop is sequential.  Whether an update starting
 // at a given stream position throws draws away depends on the stream alone, not on the walkers, so the places are
-// found ahead of the update, in parallel, in three launches per half-step:
-//   1. de_plan_kernel (diffevo.hip): walker k looks at the draws at (D+3)k + r for every shift r = 0..kDeMaxShift
-//      the walkers before it may have caused, and reports itself as a candidate when any of those starts would throw
-//      a draw away (about kDeMaxShift + 1 of the n walkers do), with its table extra[r];
-//   2. de_resolve_kernel: sorts the few candidates and walks them in order, r += extra[r] -- the only sequential part,
-//      a few dozen steps -- and hands the stream on to the next half-step;
-//   3. de_update_kernel (here): every walker finds its shift by a search in that short list (staged in LDS), jumps
-//      to its place through three table look-ups, replays its integer draws, and its lanes draw their own jitters.
+// found ahead of the update, in parallel, in two launches per half-step:
+//   1. de_plan_kernel (diffevo.hip): a wavefront per walker k looks at the draws at (D+3)k + r for every shift
+//      r = 0..kDeMaxShift the walkers before it may have caused (lane j makes draw j), and reports the walker as a
+//      candidate when any of those starts would throw a draw away (about kDeMaxShift + 1 of the n walkers), with its
+//      table extra[r];
+//   2. de_update_kernel (here): every workgroup sorts the few candidates and walks them in order, r += extra[r] -- the
+//      only sequential part, a few dozen steps from LDS (workgroup 0 also hands the stream on to the next half-step);
+//      then every walker finds its shift by a search in that short list, jumps to its place through three table
+//      look-ups, replays its integer draws, and its lanes draw their own jitters.
 // More than kDeMaxShift thrown-away draws in one half-step (expected: about one, whatever n is) raise a sticky error
 // flag the host turns into a failed run: never a silently different chain.
 //
@@ -29,7 +30,8 @@ constexpr int kDeMaxShift = 31;   // largest number of thrown-away draws inside 
 constexpr int kDeWindow = 16;     // raw draws one update's integer part may consume (2 + up to 14 thrown away)
 constexpr int kDeOverrun = 255;   // DeCand::extra value of a start whose update would not fit that window
 constexpr int kDeRaw = kDeMaxShift + 1 + kDeWindow;
-constexpr int kDeMaxCand = 512;   // candidates per half-step the lists hold (typical: kDeMaxShift + 1)
+constexpr int kDeMaxCand = 128;   // candidates per half-step the lists hold (typical: kDeMaxShift + 1)
+constexpr int kDeAccSlots = 64;   // counters an ensemble step's accepted proposals are spread over (same-address atomics serialise)
 
 enum : uint32_t
 {
@@ -43,10 +45,9 @@ struct alignas(64) DeCtl
 {
     U128 state;                  // engine state in front of this half-step's first draw
     unsigned long long extra_total;  // draws thrown away before this half-step
-    uint32_t cand_count;         // filled by the plan kernel, consumed and cleared by the resolve kernel
+    uint32_t cand_count;         // filled by this half-step's plan kernel; cleared when the previous update kernel hands over
     uint32_t error;              // kDeErr* bits, sticky
-    uint32_t plan_count;         // entries of the resolved list of this half-step
-    uint32_t pad[7];
+    uint32_t pad[8];
 };
 
 struct DeCand
@@ -55,12 +56,11 @@ struct DeCand
     uint8_t extra[kDeMaxShift + 1];  // draws thrown away by an update of walker k that starts r draws late
 };
 
-// resolved list entry, sorted by k: walkers behind k start shift_after draws late; k itself throws `own` away
+// resolved list entry (LDS), sorted by k: walkers behind k start shift_after draws late
 struct DePlan
 {
     uint32_t k;
-    uint16_t shift_after;
-    uint16_t own;
+    uint32_t shift_after;
 };
 
 template <class T>
@@ -71,13 +71,15 @@ struct DeArgs
     uint32_t* n_accept;     // [W]
     const T* calc_params;
     const DeCtl* ctl;       // this half-step's
-    const DePlan* plan;     // [kDeMaxCand]
+    DeCtl* ctl_next;        // the next half-step's: written by workgroup 0
+    const DeCand* cand;     // [kDeMaxCand] candidates of this half-step, unordered
+    Affine128 half_jump;    // (D+3)*n draws
     const Affine128* jump_hi;     // [ceil(n/256)]  (D+3)*256*m draws
     const Affine128* jump_lo;     // [256]          (D+3)*j draws
     const Affine128* jump_small;  // [D + kDeRaw + 1]  j draws
     Diag* diag;
     T* chain;               // device chain, or nullptr
-    uint32_t* accepted;     // accepted proposals of this ensemble step (one counter), or nullptr
+    uint32_t* accepted;     // accepted proposals of this ensemble step ([kDeAccSlots] counters, summed by the host), or nullptr
     long long save_slot;    // >= 0: store the rows into chain[save_slot]
     uint64_t threshold;     // (2^64 - n) mod n
     U128 inc;               // pcg stream increment
@@ -95,15 +97,70 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
     T* sh_block = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::block_offset());
     __shared__ DePlan sh_plan[kDeMaxCand];
+    __shared__ uint32_t sh_k[kDeMaxCand];
+    __shared__ uint32_t sh_order[kDeMaxCand];
+    __shared__ uint32_t sh_extra[kDeMaxCand][(kDeMaxShift + 1) / 4];  // the candidates' tables: the walk never leaves LDS
+    __shared__ Affine128 sh_small[kDeMaxShift + 1];  // the jump of `shift` draws: read right behind the search, from LDS
+    constexpr int kThreads = 64 * kWavesPerBlock;
     const int dims = a.dims, n = a.n;
     const bool vec_ok = a.vec_ok != 0;
     const bool has_block_scratch = Calc::block_scratch_elems(dims) != 0;
     typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
+    Calc::block_prefetch(calc_pf, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
     const DeCtl ctl = *a.ctl;
-    const int plan_count = (int)ctl.plan_count;
-    for (int j = threadIdx.x; j < plan_count; j += 64 * kWavesPerBlock) sh_plan[j] = a.plan[j];
-    Calc::block_commit(calc_pf, sh_block, a.calc_params, dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
+    const int plan_count = (int)(ctl.cand_count < (uint32_t)kDeMaxCand ? ctl.cand_count : (uint32_t)kDeMaxCand);
+    for (int j = threadIdx.x; j < plan_count; j += kThreads) sh_k[j] = a.cand[j].k;
+    for (int t = threadIdx.x; t < plan_count * ((kDeMaxShift + 1) / 4); t += kThreads)
+    {
+        const int j = t / ((kDeMaxShift + 1) / 4), q = t % ((kDeMaxShift + 1) / 4);
+        sh_extra[j][q] = reinterpret_cast<const uint32_t*>(a.cand[j].extra)[q];
+    }
+    if (threadIdx.x <= kDeMaxShift) sh_small[threadIdx.x] = a.jump_small[threadIdx.x];
+    Calc::block_commit(calc_pf, sh_block, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
+    __syncthreads();
+    for (int j = threadIdx.x; j < plan_count; j += kThreads)
+    {
+        int rank = 0;
+        const uint32_t mine = sh_k[j];
+        for (int i = 0; i < plan_count; ++i) rank += sh_k[i] < mine ? 1 : 0;  // (walker indices are distinct)
+        sh_order[rank] = (uint32_t)j;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        // the sequential part: the candidates in walker order, each starting as late as those before it made it
+        int r = 0;
+        uint32_t err = ctl.error;
+        for (int j = 0; j < plan_count; ++j)
+        {
+            const int cj = (int)sh_order[j];
+            int own = (int)((sh_extra[cj][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+            if (own == kDeOverrun)
+            {
+                err |= kDeErrWindow;
+                own = 0;
+            }
+            r += own;
+            if (r > kDeMaxShift)
+            {
+                err |= kDeErrShift;
+                r = kDeMaxShift;
+            }
+            sh_plan[j].k = sh_k[cj];
+            sh_plan[j].shift_after = (uint32_t)r;
+        }
+        if (blockIdx.x == 0)
+        {
+            // hand the stream on (the next half-step's record is not in use: its last reader was the previous update)
+            DeCtl nx;
+            nx.state = apply(sh_small[r], apply(a.half_jump, ctl.state));
+            nx.extra_total = ctl.extra_total + (unsigned long long)r;
+            nx.cand_count = 0;
+            nx.error = err;
+            for (int q = 0; q < 8; ++q) nx.pad[q] = 0;
+            *a.ctl_next = nx;
+        }
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -142,7 +199,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
             hi = mid;
     }
     const int shift = lo > 0 ? (int)sh_plan[lo - 1].shift_after : 0;
-    U128 s = apply(a.jump_small[shift], apply(j_lo, apply(j_hi, ctl.state)));
+    // (the uniform jumps of this lane do not depend on the search: fetched here, in its shadow)
+    const Affine128 j_uni = a.jump_small[i0 < dims ? i0 : dims], j_exp = a.jump_small[dims];
+    U128 s = apply(sh_small[shift], apply(j_lo, apply(j_hi, ctl.state)));
 
     // ind1, ind2 (DifferentialEvolution.h:83-87), thrown-away draws included; the plan bounds the loops
     const bool pow2 = (n & (n - 1)) == 0;
@@ -174,8 +233,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
 
     // the jitters of this lane's elements (draws i0 .. i0+EPL-1 behind the integer draws) and the exponential
     // (draw D behind them): MultiSampler.h:66,80
-    U128 su = apply(a.jump_small[i0 < dims ? i0 : dims], s);
-    U128 se = pcg_step(apply(a.jump_small[dims], s), a.inc);
+    U128 su = apply(j_uni, s);
+    U128 se = pcg_step(apply(j_exp, s), a.inc);
     T prop[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
@@ -218,7 +277,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
             store_slice<T, EPL>(crow, i0, dims, vec_ok, own);
     }
     const unsigned acc = (unsigned)__popcll(__ballot(accept && sub == 0));
-    if (a.accepted != nullptr && lane == 0 && acc != 0) atomicAdd(a.accepted, acc);
+    if (a.accepted != nullptr && lane == 0 && acc != 0) atomicAdd(a.accepted + ((blockIdx.x * kWavesPerBlock + wib) & (kDeAccSlots - 1)), acc);
 }
 
 }  // namespace mcmcpp

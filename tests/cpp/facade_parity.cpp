@@ -2,7 +2,7 @@
 // reference: the same user code one would write against the reference's EnsembleSampler /
 // ParallelEnsembleSampler + StretchMove, linked against libmcmcpp_hip.so instead.
 //
-//   facade_parity <fixture.bin>
+//   facade_parity <fixture.bin> [de]        (de: the fixture is a Mover::DifferentialEvolution run)
 // fixture: int32 W, D, steps, slicing, calc, nparams, nkept, dtype (0 = double, 1 = float); T params[nparams];
 //          T pos[W*D]; T logp[W]; int32 kept_step[nkept]; T kept[nkept][W*D]; uint64 accepted_total, total_steps
 #include <cstdint>
@@ -13,6 +13,7 @@
 
 #include "Device/Calculators.h"
 #include "EnsembleSampler.h"
+#include "Movers/DifferentialEvolution.h"
 #include "Movers/StretchMove.h"
 #include "ParallelEnsembleSampler.h"
 
@@ -117,10 +118,29 @@ static void checkChain(Sampler& s, const Fixture<T>& f)
     CHECK(sets == (long)(f.steps + 1) * f.W);
 }
 
-template <class T, class Calc>
+struct UseStretch
+{
+    template <class T, class Calc>
+    struct Of
+    {
+        typedef Mover::StretchMove<T, Calc> type;
+    };
+    static const bool drawsVary = false;
+};
+struct UseDiffEvo
+{
+    template <class T, class Calc>
+    struct Of
+    {
+        typedef Mover::DifferentialEvolution<T, Calc> type;
+    };
+    static const bool drawsVary = true;  // the mover throws draws away: the redraw counter is not an error count
+};
+
+template <class Sel, class T, class Calc>
 static void runCase(const Fixture<T>& f, Calc calc)
 {
-    typedef Mover::StretchMove<T, Calc> MoverType;
+    typedef typename Sel::template Of<T, Calc>::type MoverType;
     std::vector<T> pos(f.pos), logp(f.logp);
     // the initial auxValues are what user code computes with the Calculator (reference test main.cpp:141-205)
     for (int w = 0; w < f.W; ++w) CHECK(calc.calcLogPostProb(pos.data() + (size_t)w * f.D) == f.logp[w]);
@@ -137,7 +157,7 @@ static void runCase(const Fixture<T>& f, Calc calc)
         CHECK(sampler.getAcceptanceFraction() == (T)f.acceptedTotal / (T)f.totalSteps);
         std::uint64_t ties = 1, redraws = 1;
         sampler.diagnostics(&ties, &redraws);
-        CHECK(ties == 0 && redraws == 0);
+        CHECK(ties == 0 && (Sel::drawsVary || redraws == 0));
         // reset keeps the walkers, forgets chain and counters (EnsembleSampler.h:312-322)
         std::vector<T> now((size_t)f.W * f.D);
         sampler.currentState(now.data(), nullptr, nullptr);
@@ -176,16 +196,16 @@ static void runCase(const Fixture<T>& f, Calc calc)
     }
 }
 
-template <class T>
+template <class Sel, class T>
 static int runFixture(const char* path)
 {
     const Fixture<T> f = load<T>(path);
     switch (f.calc)
     {
-    case Device::IsoGaussianId: runCase<T>(f, Device::IsoGaussian<T>(f.D)); break;
-    case Device::DenseGaussianId: runCase<T>(f, Device::DenseGaussian<T>(f.D, f.params.data())); break;
-    case Device::RosenbrockId: runCase<T>(f, Device::Rosenbrock<T>(f.D, f.params[0], f.params[1], f.params[2])); break;
-    case Device::SkewedGaussian2DId: runCase<T>(f, Device::SkewedGaussian2D<T>(f.params[0])); break;
+    case Device::IsoGaussianId: runCase<Sel, T>(f, Device::IsoGaussian<T>(f.D)); break;
+    case Device::DenseGaussianId: runCase<Sel, T>(f, Device::DenseGaussian<T>(f.D, f.params.data())); break;
+    case Device::RosenbrockId: runCase<Sel, T>(f, Device::Rosenbrock<T>(f.D, f.params[0], f.params[1], f.params[2])); break;
+    case Device::SkewedGaussian2DId: runCase<Sel, T>(f, Device::SkewedGaussian2D<T>(f.params[0])); break;
     default: std::printf("unknown calculator %d\n", f.calc); return 2;
     }
     if (failures == 0)
@@ -201,5 +221,7 @@ int main(int argc, char** argv)
         std::printf("usage: facade_parity fixture.bin\n");
         return 2;
     }
-    return peekDtype(argv[1]) == 0 ? runFixture<double>(argv[1]) : runFixture<float>(argv[1]);
+    const bool de = argc > 2 && std::strcmp(argv[2], "de") == 0;
+    if (de) return peekDtype(argv[1]) == 0 ? runFixture<UseDiffEvo, double>(argv[1]) : runFixture<UseDiffEvo, float>(argv[1]);
+    return peekDtype(argv[1]) == 0 ? runFixture<UseStretch, double>(argv[1]) : runFixture<UseStretch, float>(argv[1]);
 }

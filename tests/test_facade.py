@@ -75,6 +75,17 @@ def test_facade_matches_reference_golden(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["de_iso64x4", "de_iso100x7", "de_rosen80x8", "de_dense96x16", "de_dense80x5_f32"])
+def test_facade_differential_evolution_matches_reference_golden(name, tmp_path):
+    """The same program with Mover::DifferentialEvolution (include/MCMCpp/Movers/DifferentialEvolution.h)."""
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "facade_parity.cpp"), "facade_parity", link=True)
+    fx = tmp_path / (name + ".bin")
+    _write_fixture(Golden(name), fx)
+    out = subprocess.run([exe, str(fx), "de"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "facade_parity OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
 def test_example_reproduces_reference_test_output(tmp_path):
     """examples/skewed_gaussian_stretch.cpp with the reference test's initial placement prints the
     reference's acceptance line (accepted/total)."""
