@@ -55,6 +55,7 @@ struct DeCand
     uint32_t k;
     uint8_t extra[kDeMaxShift + 1];  // draws thrown away by an update of walker k that starts r draws late
 };
+static_assert(sizeof(DeCand) == 4 * (1 + (kDeMaxShift + 1) / 4), "the update kernel stages DeCand word by word");
 
 // resolved list entry (LDS), sorted by k: walkers behind k start shift_after draws late
 struct DePlan
@@ -107,14 +108,39 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     const bool has_block_scratch = Calc::block_scratch_elems(dims) != 0;
     typename Calc::Prefetch calc_pf;
     Calc::block_prefetch(calc_pf, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int sub = lane & (LPW - 1);
+    const int k = (blockIdx.x * kWavesPerBlock + wib) * WPP + lane / LPW;  // walker inside the half
+    const bool active = k < n;
+    const int kk = active ? k : 0;
+    const int half_base = a.color ? n : 0, other_base = a.color ? 0 : n;
+    const int w = half_base + kk;
+    const int i0 = sub * EPL;
+
+    // First round trip, everything that needs no other load's result: the control record, the whole candidate list (its
+    // length is in the control record: entries beyond it are stale and never looked at), and what the walker index
+    // alone addresses -- own row, log-posterior, counter, the table jumps.  They travel while the workgroup sorts and
+    // walks the candidates below.
+    // own row, log-posterior, counter: addressed by the walker index alone
+    T own[EPL];
+    load_slice<T, EPL>(a.pos + (size_t)w * dims, i0, dims, vec_ok, active, own);
+    const T lp_old = a.logp[w];
+    const uint32_t nacc_old = a.n_accept[w];
+    const Affine128 j_hi = a.jump_hi[kk >> 8], j_lo = a.jump_lo[kk & 255];
+    const Affine128 j_uni = a.jump_small[i0 < dims ? i0 : dims], j_exp = a.jump_small[dims];
     const DeCtl ctl = *a.ctl;
-    const int plan_count = (int)(ctl.cand_count < (uint32_t)kDeMaxCand ? ctl.cand_count : (uint32_t)kDeMaxCand);
-    for (int j = threadIdx.x; j < plan_count; j += kThreads) sh_k[j] = a.cand[j].k;
-    for (int t = threadIdx.x; t < plan_count * ((kDeMaxShift + 1) / 4); t += kThreads)
+    for (int t = threadIdx.x; t < kDeMaxCand * (1 + (kDeMaxShift + 1) / 4); t += kThreads)
     {
-        const int j = t / ((kDeMaxShift + 1) / 4), q = t % ((kDeMaxShift + 1) / 4);
-        sh_extra[j][q] = reinterpret_cast<const uint32_t*>(a.cand[j].extra)[q];
+        // (a DeCand is 1 + 8 words: k, extra[32])
+        const int j = t / (1 + (kDeMaxShift + 1) / 4), q = t % (1 + (kDeMaxShift + 1) / 4);
+        const uint32_t word = reinterpret_cast<const uint32_t*>(a.cand + j)[q];
+        if (q == 0)
+            sh_k[j] = word;
+        else
+            sh_extra[j][q - 1] = word;
     }
+    const int plan_count = (int)(ctl.cand_count < (uint32_t)kDeMaxCand ? ctl.cand_count : (uint32_t)kDeMaxCand);
     if (threadIdx.x <= kDeMaxShift) sh_small[threadIdx.x] = a.jump_small[threadIdx.x];
     Calc::block_commit(calc_pf, sh_block, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
     __syncthreads();
@@ -163,16 +189,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int sub = lane & (LPW - 1);
-    const int k = (blockIdx.x * kWavesPerBlock + wib) * WPP + lane / LPW;  // walker inside the half
-    const bool active = k < n;
-    const int kk = active ? k : 0;
-    const int half_base = a.color ? n : 0, other_base = a.color ? 0 : n;
-    const int w = half_base + kk;
-    const int i0 = sub * EPL;
-
     GroupCtx<T, EPL, LPW> ctx;
     ctx.sub = sub;
     ctx.dims = dims;
@@ -180,13 +196,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     ctx.stage = Calc::kNeedsStage ? &sh_stage[wib * 64 * EPL] : nullptr;
     ctx.block_scratch = has_block_scratch ? sh_block : nullptr;
     ctx.vec_ok = vec_ok;
-
-    // own row, log-posterior, counter: addressed by the walker index alone
-    T own[EPL];
-    load_slice<T, EPL>(a.pos + (size_t)w * dims, i0, dims, vec_ok, active, own);
-    const T lp_old = a.logp[w];
-    const uint32_t nacc_old = a.n_accept[w];
-    const Affine128 j_hi = a.jump_hi[kk >> 8], j_lo = a.jump_lo[kk & 255];
 
     // this walker's place in the stream: the last list entry in front of it says how late it starts
     int lo = 0, hi = plan_count;  // first entry with k' >= k
@@ -199,8 +208,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
             hi = mid;
     }
     const int shift = lo > 0 ? (int)sh_plan[lo - 1].shift_after : 0;
-    // (the uniform jumps of this lane do not depend on the search: fetched here, in its shadow)
-    const Affine128 j_uni = a.jump_small[i0 < dims ? i0 : dims], j_exp = a.jump_small[dims];
     U128 s = apply(sh_small[shift], apply(j_lo, apply(j_hi, ctl.state)));
 
     // ind1, ind2 (DifferentialEvolution.h:83-87), thrown-away draws included; the plan bounds the loops
