@@ -147,7 +147,14 @@ def make_reference_test_run():
                     "compiler contract a*b+c into FMA (e.g. -O3 -march=native) takes different accept decisions")
     with open(os.path.join(HERE, "reference_skewed_test.json"), "w") as f:
         json.dump(out, f, indent=1)
-    return out
+    # the same driver with Mover::DifferentialEvolution and slicing 10: test/sequential/SkewedGaussian/DiffEvo/src/main.cpp
+    ref = po.reference_run(W, D, po.CALC_SKEWED_GAUSSIAN_2D, np.array([0.13]), 0, pos, logp, 1, 40019, slicing=10,
+                           want_chain=False, alpha_code=2)
+    de = dict(W=W, D=D, slicing=10, stored_steps=40019, eps=0.13, accepted_total=int(ref["accepted"][-1]),
+              total_steps=int(ref["total"][-1]), seconds_reference=ref["seconds"], mover="DifferentialEvolution")
+    with open(os.path.join(HERE, "reference_skewed_diffevo_test.json"), "w") as f:
+        json.dump(de, f, indent=1)
+    return out, de
 
 
 def make_covariance():

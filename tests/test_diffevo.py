@@ -52,6 +52,21 @@ def test_oracle_differential_evolution_has_no_counter_mode():
         orc.run(2, mode=po.MODE_COUNTER)
 
 
+def test_oracle_reproduces_the_references_own_diffevo_test_run():
+    """test/sequential/SkewedGaussian/DiffEvo/src/main.cpp (320 x 2 skewed Gaussian, slicing 10, 40 019 stored steps) end to
+    end: accepted/total as the reference computes them (tests/golden/reference_skewed_diffevo_test.json)."""
+    import json
+    import os
+    from tests.goldens import GOLDEN_DIR
+    want = json.load(open(os.path.join(GOLDEN_DIR, "reference_skewed_diffevo_test.json")))
+    g = Golden("skewed320x2")  # the test's initial placement
+    orc = po.Oracle(g.W, g.D, g.calc, g.params, seed=0, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
+    orc.set_state(g.init_pos, g.init_logp)
+    _, acc = orc.run(want["stored_steps"], interval=want["slicing"], save_chain=False)
+    assert int(acc.sum()) + g.W == want["accepted_total"]
+    assert g.W * (1 + want["stored_steps"] * want["slicing"]) == want["total_steps"]
+
+
 @pytest.mark.skipif(not po.reference_available(), reason="oracle/_ref not built (no /root/reference here)")
 def test_oracle_differential_evolution_against_the_live_reference():
     W, D = 36, 5

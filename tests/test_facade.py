@@ -37,6 +37,7 @@ def test_chain_and_iterators():
 def test_facade_compiles_and_links_against_the_c_abi():
     _compile(os.path.join(ROOT, "tests", "cpp", "facade_parity.cpp"), "facade_parity", link=True)
     _compile(os.path.join(ROOT, "examples", "skewed_gaussian_stretch.cpp"), "skewed_gaussian_stretch", link=True)
+    _compile(os.path.join(ROOT, "examples", "skewed_gaussian_diffevo.cpp"), "skewed_gaussian_diffevo", link=True)
 
 
 def test_non_device_calculator_is_rejected_at_compile_time(tmp_path):
@@ -92,6 +93,20 @@ def test_example_reproduces_reference_test_output(tmp_path):
     import json
     want = json.load(open(os.path.join(GOLDEN_DIR, "reference_skewed_test.json")))
     exe = _compile(os.path.join(ROOT, "examples", "skewed_gaussian_stretch.cpp"), "skewed_gaussian_stretch", link=True)
+    init = tmp_path / "init.bin"
+    init.write_bytes(np.asarray(Golden("skewed320x2").init_pos, dtype=np.float64).tobytes())
+    out = subprocess.run([exe, str(want["stored_steps"]), str(init)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Acceptance Fraction: %d/%d" % (want["accepted_total"], want["total_steps"]) in out.stdout, out.stdout
+
+
+@pytest.mark.gpu
+def test_diffevo_example_reproduces_reference_test_output(tmp_path):
+    """examples/skewed_gaussian_diffevo.cpp -- the reference's SkewedGaussian/DiffEvo test (320 x 2, slicing 10, 40 019 stored
+    steps) -- with the reference test's initial placement prints the acceptance line the reference computes."""
+    import json
+    want = json.load(open(os.path.join(GOLDEN_DIR, "reference_skewed_diffevo_test.json")))
+    exe = _compile(os.path.join(ROOT, "examples", "skewed_gaussian_diffevo.cpp"), "skewed_gaussian_diffevo", link=True)
     init = tmp_path / "init.bin"
     init.write_bytes(np.asarray(Golden("skewed320x2").init_pos, dtype=np.float64).tobytes())
     out = subprocess.run([exe, str(want["stored_steps"]), str(init)], capture_output=True, text=True, timeout=900)

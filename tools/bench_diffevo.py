@@ -24,6 +24,7 @@ def main():
     lp = s.calc_logp(pos)
     s.set_state(pos, lp)
     s.run(1, 50, save_chain=False)
+    steps = max(100, steps)
     t0 = time.perf_counter()
     _, acc = s.run(steps // 100, 100, save_chain=True)
     dev = time.perf_counter() - t0
@@ -31,14 +32,14 @@ def main():
     c = s.counters()
     line = "differential evolution %d x %d dense Gaussian: device %.3e walker-steps/s (%.1f us per ensemble step, 4 launches), acceptance %.3f, " \
            "%d draws thrown away in %d half-steps" % (W, D, W * done / dev, dev / done * 1e6, acc.sum() / (W * done), c["redraws"], 2 * (done + 50))
-    cpu_steps = 30
+    cpu_steps = max(1, min(30, (30 * 16384) // W))
     orc = po.Oracle(W, D, po.CALC_DENSE_GAUSSIAN, P, seed=0, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
     orc.set_state(pos, lp)
     t0 = time.perf_counter()
     orc.run(cpu_steps, 1, save_chain=False)
     port = W * cpu_steps / (time.perf_counter() - t0)
     line += "; oracle on one core %.3e" % port
-    if po.reference_available():
+    if po.reference_available() and W * D <= 16384 * 32:  # (the reference's Chain overflows its 32-bit indices beyond that)
         r = po.reference_run(W, D, po.CALC_DENSE_GAUSSIAN, P, 0, pos, lp, 1, cpu_steps, want_chain=False, alpha_code=2)
         line += "; reference (one core) %.3e" % (W * cpu_steps / r["seconds"])
     print(line)
