@@ -86,25 +86,6 @@ de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine1
     }
 }
 
-int pow2_at_least(int v)
-{
-    int p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-int ilog2(int v)
-{
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
-Affine128 compose(const Affine128& g, const Affine128& f)  // g after f
-{
-    Affine128 r;
-    r.mult = mul128(g.mult, f.mult);
-    r.plus = add128(mul128(g.mult, f.plus), g.plus);
-    return r;
-}
 
 template <class T>
 class DeSampler final : public mcmcpp_hip_sampler

@@ -34,26 +34,7 @@ namespace
 {
 thread_local std::string g_create_error;
 
-int pow2_at_least(int v)
-{
-    int p = 1;
-    while (p < v) p <<= 1;
-    return p;
-}
-int ilog2(int v)
-{
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
-}
 
-Affine128 compose(const Affine128& g, const Affine128& f)  // g after f
-{
-    Affine128 r;
-    r.mult = mul128(g.mult, f.mult);
-    r.plus = add128(mul128(g.mult, f.plus), g.plus);
-    return r;
-}
 
 // memcpy of a large block split over a few threads (the un-overlapped tail of a run's chain download: a single core
 // moves ~12 GB/s into pageable memory)

@@ -49,8 +49,30 @@ struct mcmcpp_hip_sampler
     } while (0)
 
 
+#include "pcg128.hpp"
+
 namespace mcmcpp
 {
+inline int pow2_at_least(int v)
+{
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+inline int ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+inline Affine128 compose(const Affine128& g, const Affine128& f)  // g after f
+{
+    Affine128 r;
+    r.mult = mul128(g.mult, f.mult);
+    r.plus = add128(mul128(g.mult, f.plus), g.plus);
+    return r;
+}
+
 // launch table (LaunchTable<double> / LaunchTable<float>) of a built-in or registered calculator, or nullptr
 const void* launch_table_lookup(int dtype, int calc_id);
 // Mover::DifferentialEvolution (diffevo.hip); *rc receives the init result, the handle carries the message

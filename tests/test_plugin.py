@@ -53,12 +53,14 @@ def test_registration_rules(plugin):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mover", [capi.MOVER_STRETCH, capi.MOVER_DIFFERENTIAL_EVOLUTION])
 @pytest.mark.parametrize("dtype", [po.F64, po.F32])
-def test_plugin_clone_follows_the_builtin_trajectory(plugin, dtype):
+def test_plugin_clone_follows_the_builtin_trajectory(plugin, dtype, mover):
+    # (a plug-in's launch table carries the kernels of both movers)
     W, D = 2048, 24
     pos = po.init_positions(dtype, W, D, salt=6)
-    builtin = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, seed=2, dtype=dtype)
-    clone = capi.HipSampler(W, D, ISO_CLONE, seed=2, dtype=dtype)
+    builtin = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, seed=2, dtype=dtype, mover=mover)
+    clone = capi.HipSampler(W, D, ISO_CLONE, seed=2, dtype=dtype, mover=mover)
     logp = builtin.calc_logp(pos)
     np.testing.assert_array_equal(clone.calc_logp(pos), logp)
     builtin.set_state(pos, logp)
