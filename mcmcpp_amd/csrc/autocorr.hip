@@ -137,9 +137,28 @@ __global__ void __launch_bounds__(kAcThreads) ac_accumulate_kernel(const T* acov
     if (idx >= (long long)D * n) return;
     const int p = (int)(idx / n), i = (int)(idx % n);
     T s = sum[idx], c = comp[idx];
-    for (int w = 0; w < chunk_walkers; ++w)
+    // eight loads in flight per thread: the additions have to follow one another, the loads do not
+    constexpr int kBatch = 8;
+    const size_t walker_stride = (size_t)D * n;
+    const T* src = acov + (size_t)p * n + i;
+    int w = 0;
+    for (; w + kBatch <= chunk_walkers; w += kBatch)
     {
-        const T value = acov[((size_t)w * D + p) * n + i] + c;
+        T v[kBatch];
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b) v[b] = src[(size_t)(w + b) * walker_stride];
+#pragma unroll
+        for (int b = 0; b < kBatch; ++b)
+        {
+            const T value = v[b] + c;
+            const T temp = s + value;
+            c = (temp - s) - value;
+            s = temp;
+        }
+    }
+    for (; w < chunk_walkers; ++w)
+    {
+        const T value = src[(size_t)w * walker_stride] + c;
         const T temp = s + value;
         c = (temp - s) - value;
         s = temp;
