@@ -222,6 +222,10 @@ const char* mcmcpp_hip_moments_last_error(const mcmcpp_hip_moments* m);
  * walker's function; uninitialised memory for the first), see INTEGRATION.md 4b. */
 int mcmcpp_hip_autocorr_times(int32_t dtype, int32_t device, const void* const* steps, int64_t n_steps, int32_t num_walkers, int32_t num_params,
                               int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions);
+/* the same for a chain that already lives in device memory: n_steps contiguous stored steps ([n_steps][W][D], e.g. a device
+ * chain bound with mcmcpp_hip_bind_device_chain); no upload */
+int mcmcpp_hip_autocorr_times_device(int32_t dtype, int32_t device, const void* device_steps, int64_t n_steps, int32_t num_walkers,
+                                     int32_t num_params, int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions);
 const char* mcmcpp_hip_autocorr_last_error(void);
 
 int mcmcpp_hip_abi_version(void);

@@ -22,7 +22,7 @@ EXPORTS = [
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
     "mcmcpp_hip_moments_create", "mcmcpp_hip_moments_destroy", "mcmcpp_hip_moments_reset", "mcmcpp_hip_moments_add_steps",
     "mcmcpp_hip_moments_add_device_steps", "mcmcpp_hip_moments_finish", "mcmcpp_hip_moments_last_error",
-    "mcmcpp_hip_autocorr_times", "mcmcpp_hip_autocorr_last_error",
+    "mcmcpp_hip_autocorr_times", "mcmcpp_hip_autocorr_times_device", "mcmcpp_hip_autocorr_last_error",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
             L.mcmcpp_hip_moments_last_error.restype = C.c_char_p
         if hasattr(L, "mcmcpp_hip_autocorr_times"):
             L.mcmcpp_hip_autocorr_times.argtypes = [i32, i32, C.POINTER(vp), i64, i32, i32, i32, i32, vp, vp]
+            L.mcmcpp_hip_autocorr_times_device.argtypes = [i32, i32, vp, i64, i32, i32, i32, i32, vp, vp]
             L.mcmcpp_hip_autocorr_last_error.argtypes = []
             L.mcmcpp_hip_autocorr_last_error.restype = C.c_char_p
         _lib = L
@@ -281,3 +282,12 @@ def autocorr_times(steps, walkers_to_use=0, window_scaling=4, want_functions=Fal
     if rc != OK:
         raise HipError(rc, (lib().mcmcpp_hip_autocorr_last_error() or b"").decode())
     return (times, functions) if want_functions else times
+
+
+def autocorr_times_device(device_ptr, n_steps, W, D, dtype=F64, walkers_to_use=0, window_scaling=4, device=-1):
+    """The same for n_steps contiguous stored steps in device memory (an integer address, e.g. torch.Tensor.data_ptr())."""
+    times = np.zeros(D, np_dtype(dtype))
+    rc = lib().mcmcpp_hip_autocorr_times_device(dtype, device, C.c_void_p(device_ptr), n_steps, W, D, walkers_to_use, window_scaling, _ptr(times), None)
+    if rc != OK:
+        raise HipError(rc, (lib().mcmcpp_hip_autocorr_last_error() or b"").decode())
+    return times

@@ -255,7 +255,8 @@ struct DeviceBuffers
     } while (0)
 
 template <class T>
-int autocorr_times(const void* const* steps, int64_t n_steps, int W, int D, int use, int window_scaling, T* times, T* functions)
+// steps: n_steps host pointers, or nullptr when device_steps holds the whole [n_steps][W][D] chain in device memory
+int autocorr_times(const void* const* steps, const T* device_steps, int64_t n_steps, int W, int D, int use, int window_scaling, T* times, T* functions)
 {
     const int n = (int)n_steps;
     const size_t step_elems = (size_t)W * D;
@@ -282,19 +283,21 @@ int autocorr_times(const void* const* steps, int64_t n_steps, int W, int D, int 
     int chunk = use;
     while (chunk > 1 && ((size_t)chunk * per_walker > ((size_t)1 << 30) || (size_t)chunk * per_walker_scratch > ((size_t)2 << 30))) chunk = (chunk + 1) / 2;
 
-    T *d_steps, *d_avg, *d_tw, *d_acov, *d_sum, *d_comp, *d_times, *d_scratch = nullptr;
+    T *d_avg, *d_tw, *d_acov, *d_sum, *d_comp, *d_times, *d_scratch = nullptr;
+    T* d_upload = nullptr;
     int* d_idx;
-    if (!dev.alloc(&d_steps, (size_t)n * step_elems) || !dev.alloc(&d_avg, (size_t)use * D) || !dev.alloc(&d_tw, (size_t)fft) ||
+    if ((steps && !dev.alloc(&d_upload, (size_t)n * step_elems)) || !dev.alloc(&d_avg, (size_t)use * D) || !dev.alloc(&d_tw, (size_t)fft) ||
         !dev.alloc(&d_acov, (size_t)chunk * D * n) || !dev.alloc(&d_sum, (size_t)D * n) || !dev.alloc(&d_comp, (size_t)D * n) ||
         !dev.alloc(&d_times, (size_t)D) || !dev.alloc(&d_idx, (size_t)use) || (!lds && !dev.alloc(&d_scratch, (size_t)chunk * D * 2 * fft)))
         return ac_fail(MCMCPP_HIP_E_NOMEM, "autocorr_times: cannot allocate device memory for the chain and the work arrays");
 
+    const T* d_steps = steps ? d_upload : device_steps;
     // upload: steps that follow each other in host memory go in one copy
-    for (int64_t s = 0; s < n_steps;)
+    for (int64_t s = 0; steps && s < n_steps;)
     {
         int64_t e = s + 1;
         while (e < n_steps && static_cast<const T*>(steps[e]) == static_cast<const T*>(steps[e - 1]) + step_elems) ++e;
-        AC_TRY(hipMemcpyAsync(d_steps + (size_t)s * step_elems, steps[s], sizeof(T) * (size_t)(e - s) * step_elems, hipMemcpyHostToDevice, dev.stream));
+        AC_TRY(hipMemcpyAsync(d_upload + (size_t)s * step_elems, steps[s], sizeof(T) * (size_t)(e - s) * step_elems, hipMemcpyHostToDevice, dev.stream));
         s = e;
     }
     AC_TRY(hipMemcpyAsync(d_tw, tw.data(), sizeof(T) * tw.size(), hipMemcpyHostToDevice, dev.stream));
@@ -330,17 +333,17 @@ extern "C"
 {
 const char* mcmcpp_hip_autocorr_last_error(void) { return g_ac_error.c_str(); }
 
-int mcmcpp_hip_autocorr_times(int32_t dtype, int32_t device, const void* const* steps, int64_t n_steps, int32_t num_walkers, int32_t num_params,
-                              int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions)
+static int autocorr_entry(int32_t dtype, int32_t device, const void* const* steps, const void* device_steps, int64_t n_steps, int32_t num_walkers,
+                          int32_t num_params, int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions)
 {
-    if (!steps || !times) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: steps and times must not be NULL");
+    if ((!steps && !device_steps) || !times) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: steps and times must not be NULL");
     if ((dtype != MCMCPP_HIP_F64 && dtype != MCMCPP_HIP_F32) || num_walkers < 1 || num_params < 1)
         return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: dtype must be F64/F32, num_walkers >= 1, num_params >= 1");
     if (n_steps < 2 || n_steps > (int64_t(1) << 24)) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: 2 <= n_steps <= 2^24");
     if (walkers_to_use < 0 || walkers_to_use > num_walkers) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: 0 <= walkers_to_use <= num_walkers");
     if ((int64_t)num_params * n_steps >= (int64_t(1) << 31) || (int64_t)num_walkers * num_params >= (int64_t(1) << 31))
         return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: num_params * n_steps and num_walkers * num_params must be below 2^31");
-    for (int64_t s = 0; s < n_steps; ++s)
+    for (int64_t s = 0; steps && s < n_steps; ++s)
         if (!steps[s]) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: a step pointer is NULL");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return ac_fail(MCMCPP_HIP_E_NO_DEVICE, "no HIP device visible to this process");
@@ -352,7 +355,23 @@ int mcmcpp_hip_autocorr_times(int32_t dtype, int32_t device, const void* const* 
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ac_fail(MCMCPP_HIP_E_NO_DEVICE, "this library is built for gfx950 only");
     const int use = walkers_to_use == 0 ? num_walkers : walkers_to_use;
     if (dtype == MCMCPP_HIP_F64)
-        return autocorr_times<double>(steps, n_steps, num_walkers, num_params, use, window_scaling, static_cast<double*>(times), static_cast<double*>(functions));
-    return autocorr_times<float>(steps, n_steps, num_walkers, num_params, use, window_scaling, static_cast<float*>(times), static_cast<float*>(functions));
+        return autocorr_times<double>(steps, static_cast<const double*>(device_steps), n_steps, num_walkers, num_params, use, window_scaling,
+                                      static_cast<double*>(times), static_cast<double*>(functions));
+    return autocorr_times<float>(steps, static_cast<const float*>(device_steps), n_steps, num_walkers, num_params, use, window_scaling,
+                                 static_cast<float*>(times), static_cast<float*>(functions));
+}
+
+int mcmcpp_hip_autocorr_times(int32_t dtype, int32_t device, const void* const* steps, int64_t n_steps, int32_t num_walkers, int32_t num_params,
+                              int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions)
+{
+    if (!steps) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times: steps must not be NULL");
+    return autocorr_entry(dtype, device, steps, nullptr, n_steps, num_walkers, num_params, walkers_to_use, window_scaling, times, functions);
+}
+
+int mcmcpp_hip_autocorr_times_device(int32_t dtype, int32_t device, const void* device_steps, int64_t n_steps, int32_t num_walkers, int32_t num_params,
+                                     int32_t walkers_to_use, int32_t window_scaling, void* times, void* functions)
+{
+    if (!device_steps) return ac_fail(MCMCPP_HIP_E_ARG, "autocorr_times_device: device_steps must not be NULL");
+    return autocorr_entry(dtype, device, nullptr, device_steps, n_steps, num_walkers, num_params, walkers_to_use, window_scaling, times, functions);
 }
 }

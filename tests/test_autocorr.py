@@ -167,6 +167,16 @@ def test_device_autocorr_on_a_sampler_chain():
 
 
 @pytest.mark.gpu
+def test_device_resident_chain_gives_the_same_times():
+    import torch
+    steps = ar_chain(700, 12, 5, 8, (0.9, 0.5, 0.7, 0.2, 0.8))
+    t = torch.from_numpy(steps).cuda()
+    got = capi.autocorr_times_device(t.data_ptr(), 700, 12, 5)
+    np.testing.assert_array_equal(got, capi.autocorr_times(steps, 0, 4))
+    np.testing.assert_array_equal(got, po.autocorr_times(steps, 4))
+
+
+@pytest.mark.gpu
 def test_device_autocorr_rejects_bad_arguments():
     steps = ar_chain(10, 2, 2, 1, 0.5)
     with pytest.raises(capi.HipError):
