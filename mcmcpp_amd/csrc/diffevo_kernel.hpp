@@ -98,9 +98,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
     T* sh_block = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::block_offset());
     __shared__ DePlan sh_plan[kDeMaxCand];
-    __shared__ uint32_t sh_k[kDeMaxCand];
-    __shared__ uint32_t sh_order[kDeMaxCand];
-    __shared__ uint32_t sh_extra[kDeMaxCand][(kDeMaxShift + 1) / 4];  // the candidates' tables: the walk never leaves LDS
+    __shared__ __attribute__((aligned(16))) DeCand sh_cand[kDeMaxCand];  // as the planning left them
+    __shared__ DeCand sh_sorted[kDeMaxCand];                             // in walker order: the walk never leaves LDS
     __shared__ Affine128 sh_small[kDeMaxShift + 1];  // the jump of `shift` draws: read right behind the search, from LDS
     constexpr int kThreads = 64 * kWavesPerBlock;
     const int dims = a.dims, n = a.n;
@@ -130,26 +129,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
     const Affine128 j_hi = a.jump_hi[kk >> 8], j_lo = a.jump_lo[kk & 255];
     const Affine128 j_uni = a.jump_small[i0 < dims ? i0 : dims], j_exp = a.jump_small[dims];
     const DeCtl ctl = *a.ctl;
-    for (int t = threadIdx.x; t < kDeMaxCand * (1 + (kDeMaxShift + 1) / 4); t += kThreads)
-    {
-        // (a DeCand is 1 + 8 words: k, extra[32])
-        const int j = t / (1 + (kDeMaxShift + 1) / 4), q = t % (1 + (kDeMaxShift + 1) / 4);
-        const uint32_t word = reinterpret_cast<const uint32_t*>(a.cand + j)[q];
-        if (q == 0)
-            sh_k[j] = word;
-        else
-            sh_extra[j][q - 1] = word;
-    }
+    // the first kDeFirstCand candidates (all there are, 99.7 % of the time) in one 16-byte load per thread, issued without
+    // waiting for the count in the control record; entries beyond the count are stale and never looked at
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    constexpr int kDeFirstCand = 48;
+    constexpr int kFirstPieces = kDeFirstCand * (int)sizeof(DeCand) / 16;
+    static_assert(kDeFirstCand * sizeof(DeCand) % 16 == 0 && kFirstPieces <= kThreads, "one 16-byte piece per thread");
+    if ((int)threadIdx.x < kFirstPieces) reinterpret_cast<v4u*>(sh_cand)[threadIdx.x] = reinterpret_cast<const v4u*>(a.cand)[threadIdx.x];
     const int plan_count = (int)(ctl.cand_count < (uint32_t)kDeMaxCand ? ctl.cand_count : (uint32_t)kDeMaxCand);
     if (threadIdx.x <= kDeMaxShift) sh_small[threadIdx.x] = a.jump_small[threadIdx.x];
+    for (int t = kDeFirstCand * 9 + (int)threadIdx.x; t < plan_count * 9; t += kThreads)  // (a DeCand is nine words)
+        reinterpret_cast<uint32_t*>(sh_cand)[t] = reinterpret_cast<const uint32_t*>(a.cand)[t];
     Calc::block_commit(calc_pf, sh_block, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
     __syncthreads();
     for (int j = threadIdx.x; j < plan_count; j += kThreads)
     {
         int rank = 0;
-        const uint32_t mine = sh_k[j];
-        for (int i = 0; i < plan_count; ++i) rank += sh_k[i] < mine ? 1 : 0;  // (walker indices are distinct)
-        sh_order[rank] = (uint32_t)j;
+        const uint32_t mine = sh_cand[j].k;
+        for (int i = 0; i < plan_count; ++i) rank += sh_cand[i].k < mine ? 1 : 0;  // (walker indices are distinct)
+        sh_sorted[rank] = sh_cand[j];
     }
     __syncthreads();
     if (threadIdx.x == 0)
@@ -159,8 +157,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
         uint32_t err = ctl.error;
         for (int j = 0; j < plan_count; ++j)
         {
-            const int cj = (int)sh_order[j];
-            int own = (int)((sh_extra[cj][r >> 2] >> (8 * (r & 3))) & 0xFFu);
+            int own = (int)sh_sorted[j].extra[r];
             if (own == kDeOverrun)
             {
                 err |= kDeErrWindow;
@@ -172,7 +169,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_update_kernel(const De
                 err |= kDeErrShift;
                 r = kDeMaxShift;
             }
-            sh_plan[j].k = sh_k[cj];
+            sh_plan[j].k = sh_sorted[j].k;
             sh_plan[j].shift_after = (uint32_t)r;
         }
         if (blockIdx.x == 0)
