@@ -56,27 +56,73 @@ __global__ void __launch_bounds__(kAcThreads) ac_chain_average_kernel(const T* s
     avg[j] = sum / (T)n;
 }
 
-// one pass of the iterative Cooley-Tukey transform over bit-reversed input (AutoCov.h:166-216); sign -1 forward, +1 inverse
+// The iterative Cooley-Tukey transform over bit-reversed input (AutoCov.h:166-216); sign -1 forward, +1 inverse.
+// One butterfly of stage s: (x[i0], x[i1]) <- (x[i0] + w x[i1], x[i0] - w x[i1]), w = tw[j << (lg - s)], i1 = i0 + 2^(s-1).
+// Two stages at a time: a thread takes the four elements i, i+m, i+2m, i+3m (m = 2^(s-1)) that stages s and s+1 combine
+// among themselves and runs the reference's four butterflies on them in registers, in the reference's order of
+// operations -- same roundings, half the LDS traffic and half the workgroup barriers.  A last single stage when lg is odd.
+template <class T>
+__device__ __forceinline__ void ac_butterfly(T wr, T wi, T& ar, T& ai, T& br, T& bi)
+{
+    const T t1r = wr * br - wi * bi, t1i = wr * bi + wi * br;
+    const T t2r = ar, t2i = ai;
+    ar = t2r + t1r;
+    ai = t2i + t1i;
+    br = t2r - t1r;
+    bi = t2i - t1i;
+}
+
 template <class T>
 __device__ __forceinline__ void ac_fft_pass(T* re, T* im, int lg, const T* __restrict__ tw, T sign)
 {
-    const int half = 1 << (lg - 1);
-    for (int s = 1; s <= lg; ++s)
+    const int quarter = 1 << (lg > 1 ? lg - 2 : 0);
+    int s = 1;
+    for (; s + 1 <= lg; s += 2)
     {
+        const int m = 1 << (s - 1);
+        for (int b = threadIdx.x; b < quarter; b += kAcThreads)
+        {
+            const int j = b & (m - 1);
+            const int i = ((b >> (s - 1)) << (s + 1)) + j;
+            // stage s: (i, i+m) and (i+2m, i+3m) with twiddle index j << (lg - s)
+            const int t_a = j << (lg - s);
+            const T war = tw[2 * t_a], wai = sign * tw[2 * t_a + 1];
+            T x0r = re[i], x0i = im[i], x1r = re[i + m], x1i = im[i + m];
+            T x2r = re[i + 2 * m], x2i = im[i + 2 * m], x3r = re[i + 3 * m], x3i = im[i + 3 * m];
+            ac_butterfly(war, wai, x0r, x0i, x1r, x1i);
+            ac_butterfly(war, wai, x2r, x2i, x3r, x3i);
+            // stage s+1: (i, i+2m) with index j << (lg - s - 1), (i+m, i+3m) with index (j + m) << (lg - s - 1)
+            const int t_b = j << (lg - s - 1), t_c = (j + m) << (lg - s - 1);
+            const T wbr = tw[2 * t_b], wbi = sign * tw[2 * t_b + 1];
+            const T wcr = tw[2 * t_c], wci = sign * tw[2 * t_c + 1];
+            ac_butterfly(wbr, wbi, x0r, x0i, x2r, x2i);
+            ac_butterfly(wcr, wci, x1r, x1i, x3r, x3i);
+            re[i] = x0r;
+            im[i] = x0i;
+            re[i + m] = x1r;
+            im[i + m] = x1i;
+            re[i + 2 * m] = x2r;
+            im[i + 2 * m] = x2i;
+            re[i + 3 * m] = x3r;
+            im[i + 3 * m] = x3i;
+        }
+        __syncthreads();
+    }
+    if (s == lg)
+    {
+        const int half = 1 << (lg - 1);
         const int m2 = 1 << (s - 1);
         for (int b = threadIdx.x; b < half; b += kAcThreads)
         {
             const int j = b & (m2 - 1);
             const int i0 = ((b >> (s - 1)) << s) + j, i1 = i0 + m2;
             const int ti = j << (lg - s);
-            const T wr = tw[2 * ti], wi = sign * tw[2 * ti + 1];
-            const T br = re[i1], bi = im[i1];
-            const T t1r = wr * br - wi * bi, t1i = wr * bi + wi * br;
-            const T t2r = re[i0], t2i = im[i0];
-            re[i0] = t2r + t1r;
-            im[i0] = t2i + t1i;
-            re[i1] = t2r - t1r;
-            im[i1] = t2i - t1i;
+            T ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+            ac_butterfly(tw[2 * ti], sign * tw[2 * ti + 1], ar, ai, br, bi);
+            re[i0] = ar;
+            im[i0] = ai;
+            re[i1] = br;
+            im[i1] = bi;
         }
         __syncthreads();
     }
