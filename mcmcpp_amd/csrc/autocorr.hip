@@ -9,7 +9,7 @@
 //   * the stored steps ([n][W][D], host memory) are uploaded once (288 GB of HBM: a whole chain fits);
 //   * one thread per series forms the Kahan average in the reference's order (coalesced across series);
 //   * one workgroup per series runs the two transforms in LDS (split real/imaginary arrays, 256 threads sharing the
-//     fft/2 butterflies of a stage), W * D workgroups in flight; series too long for 64 KB of LDS use a scratch array in
+//     butterflies, two stages per pass), W * D workgroups in flight; series too long for 64 KB of LDS use a scratch array in
 //     global memory with the same code;
 //   * the sum over walkers runs one thread per (parameter, lag), walkers in the reference's order;
 //   * the windowed sum is sequential by nature: one thread per parameter, fed from LDS tiles.
