@@ -212,13 +212,20 @@ public:
         if (total == 0) return MCMCPP_HIP_OK;
         const auto t0 = std::chrono::steady_clock::now();
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
-        // stored steps leave in pieces of at most 256 MiB of device chain
+        // stored steps leave in pieces of at most 256 MiB of device chain and 64 MiB of accepted counters
         int64_t piece = n_saved;
+        if (accepted_per_step)
+        {
+            const int64_t per_stored = (int64_t)interval * kDeAccSlots * (int64_t)sizeof(uint32_t);
+            if (per_stored > ((int64_t)1 << 30))
+                return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: interval %d is too large to report accepted counts per step; pass NULL for accepted_per_step", interval);
+            const int64_t fit = ((int64_t)64 << 20) / per_stored;
+            if (piece > fit) piece = fit < 1 ? 1 : fit;
+        }
         if (chain_out)
         {
-            piece = (int64_t)(((size_t)256 << 20) / step_bytes);
-            if (piece < 1) piece = 1;
-            if (piece > n_saved) piece = n_saved;
+            const int64_t fit = (int64_t)(((size_t)256 << 20) / step_bytes);
+            if (piece > fit) piece = fit < 1 ? 1 : fit;
             if ((size_t)piece * step_bytes > chain_bytes)
             {
                 if (d_chain) HIP_TRY(hipFree(d_chain));

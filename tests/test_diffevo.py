@@ -163,6 +163,23 @@ def test_device_differential_evolution_dense_c2_shape_statistics():
 
 
 @pytest.mark.gpu
+def test_device_differential_evolution_long_intervals_in_pieces():
+    # 5 stored steps 30 000 ensemble steps apart: the accepted counters leave the device in several pieces
+    W, D, n_saved, interval = 14, 3, 5, 30000
+    pos = po.init_positions(po.F64, W, D, salt=2)
+    orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=4, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
+    lp = orc.logp(pos)
+    orc.set_state(pos, lp)
+    want_chain, want_acc = orc.run(n_saved, interval)
+    s = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=4, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    s.set_state(pos, lp)
+    chain, acc = s.run(n_saved, interval)
+    np.testing.assert_array_equal(chain, want_chain)
+    np.testing.assert_array_equal(acc, want_acc)
+    assert s.counters()["redraws"] == orc.redraws
+
+
+@pytest.mark.gpu
 def test_device_differential_evolution_refuses_what_it_cannot_do():
     s = capi.HipSampler(64, 4, capi.CALC_ISO_GAUSSIAN, None, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
     pos = po.init_positions(po.F64, 64, 4)
