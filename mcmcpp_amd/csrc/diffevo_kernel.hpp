@@ -27,7 +27,8 @@
 namespace mcmcpp
 {
 constexpr int kDeMaxShift = 31;   // largest number of thrown-away draws inside one half-step that is followed exactly
-constexpr int kDeWindow = 16;     // raw draws one update's integer part may consume (2 + up to 14 thrown away)
+constexpr int kDeWindow = 32;     // raw draws one update's integer part may consume (2 + up to 30 thrown away: even two
+                                  // walkers per half, where every second ind2 collides, overrun once in 1e9 updates)
 constexpr int kDeOverrun = 255;   // DeCand::extra value of a start whose update would not fit that window
 constexpr int kDeRaw = kDeMaxShift + 1 + kDeWindow;
 constexpr int kDeMaxCand = 128;   // candidates per half-step the lists hold (typical: kDeMaxShift + 1)

@@ -119,7 +119,7 @@ def test_device_differential_evolution_resumes_across_calls():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,D,calc,params,dt,steps,interval", [
-    (8, 1, po.CALC_ISO_GAUSSIAN, None, po.F64, 300, 1), (10, 2, po.CALC_ISO_GAUSSIAN, None, po.F64, 200, 3),
+    (4, 1, po.CALC_ISO_GAUSSIAN, None, po.F64, 2000, 1), (8, 1, po.CALC_ISO_GAUSSIAN, None, po.F64, 300, 1), (10, 2, po.CALC_ISO_GAUSSIAN, None, po.F64, 200, 3),
     (40, 3, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 150, 1), (70, 33, po.CALC_ISO_GAUSSIAN, None, po.F64, 60, 2),
     (140, 64, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 40, 1), (300, 130, po.CALC_ISO_GAUSSIAN, None, po.F64, 20, 1),
     (600, 257, po.CALC_ISO_GAUSSIAN, None, po.F64, 8, 1), (1026, 32, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 40, 1),

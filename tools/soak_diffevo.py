@@ -15,7 +15,7 @@ from oracle import pyoracle as po  # noqa: E402
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
     bad = 0
-    for W, D, calc, params in [(14, 3, po.CALC_ISO_GAUSSIAN, None), (8, 1, po.CALC_ISO_GAUSSIAN, None), (100, 7, po.CALC_ISO_GAUSSIAN, None),
+    for W, D, calc, params in [(4, 1, po.CALC_ISO_GAUSSIAN, None), (14, 3, po.CALC_ISO_GAUSSIAN, None), (8, 1, po.CALC_ISO_GAUSSIAN, None), (100, 7, po.CALC_ISO_GAUSSIAN, None),
                                (320, 2, po.CALC_SKEWED_GAUSSIAN_2D, [0.13]), (1026, 16, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05]),
                                (4096, 32, po.CALC_ISO_GAUSSIAN, None)]:
         n_steps = steps if W <= 400 else steps // 10
