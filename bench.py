@@ -5,7 +5,7 @@
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): 16 384 walkers x 32 dims, correlated Gaussian
 log-posterior (Sigma_ij = 0.5^|i-j|, dense 32x32 precision matrix), fp64, StretchMove, seed = rank.
-One bench "step" = one runMCMC batch of `--batch` ensemble steps (default 1000: 10 stored steps at
+One bench "step" = one runMCMC batch of `--batch` ensemble steps (default 2000, C2's run length: 20 stored steps at
 slicing interval 100, stored steps downloaded to the host inside the timed region; everything else stays
 resident in HBM).  For N > 1 every rank runs its own independent chain of the same size on its own GPU
 (BASELINE.json configs[3]: no data-path collective; weak scaling); the value is the sum over ranks
@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1000, help="ensemble steps per bench step")
+    ap.add_argument("--batch", type=int, default=2000, help="ensemble steps per bench step (SURVEY.md 8d: C2 runs 2 000 steps)")
     ap.add_argument("--interval", type=int, default=100, help="slicing interval (one stored step per interval)")
     ap.add_argument("--walkers", type=int, default=16384)
     ap.add_argument("--dims", type=int, default=32)
