@@ -260,7 +260,7 @@ public:
 
         {
             // upper bound of everything carved below (each piece rounded up to 256 bytes)
-            const size_t graph_len = (size_t)(c.graph_steps == 0 ? env_long("MCMCPP_HIP_GRAPH_STEPS", 128) : (c.graph_steps > 0 ? c.graph_steps : 1));
+            const size_t graph_len = (size_t)(c.graph_steps == 0 ? default_graph_steps() : (c.graph_steps > 0 ? c.graph_steps : 1));
             const size_t waves_bound = (size_t)n + 64;  // no kernel uses more wavefronts per colour than walkers
             size_t need = 2 * sizeof(T) * (size_t)W * D                 // pos, pos_alt
                           + sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W + tables_total_bytes(n, true)
@@ -360,7 +360,7 @@ public:
             HIP_TRY(hipMemcpy(d_task_jump, tj.data(), sizeof(Affine128) * tj.size(), hipMemcpyHostToDevice));
         }
 
-        graph_steps = c.graph_steps == 0 ? (int)env_long("MCMCPP_HIP_GRAPH_STEPS", 128) : c.graph_steps;
+        graph_steps = c.graph_steps == 0 ? (int)default_graph_steps() : c.graph_steps;
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
         if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;
@@ -369,6 +369,12 @@ public:
         chain_subchunk_bytes = (size_t)env_long("MCMCPP_HIP_CHAIN_SUBCHUNK_MB", 32) << 20;
         return MCMCPP_HIP_OK;
     }
+
+    // Ensemble steps per hipGraph replay.  A boundary between two replays costs a few microseconds of the launch
+    // sequence: ensembles small enough for one launch per step (5.6 us each) take 300 per replay -- with the bench's
+    // slicing interval of 100 that is three stored steps per replay, as many as the forwarding ring allows; measured 1.5 %
+    // over 128 -- larger ones, whose launches are long and whose per-step counters grow with the walker count, 128.
+    long default_graph_steps() const { return env_long("MCMCPP_HIP_GRAPH_STEPS", W <= 32768 ? 300 : 128); }
 
     // Everything a step launch touches lives in ONE device allocation, carved here (one allocation, one free; tried as
     // a way to make the cold first accesses of a launch cheaper through fewer address translations: no measurable
