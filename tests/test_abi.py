@@ -27,6 +27,16 @@ def test_exports_every_declared_symbol(lib):
     assert lib.mcmcpp_hip_abi_version() == 1
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/mcmcpp_hip.h compiles as C99 (any FFI generator can read it)."""
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "mcmcpp_hip.h"\nint main(void) { mcmcpp_hip_config c; c.mover = MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION; '
+                   'return (int)sizeof(c) == 0; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o",
+                           str(tmp_path / "hdr.o")])
+
+
 def test_config_struct_matches_header(lib):
     # struct_size is checked by the library: a python/C layout mismatch would be rejected here
     cfg = capi.Config(C.sizeof(capi.Config) - 4, 0, 64, 4, 0, 0, None, 0, 0, -1, 0, 0, 0, 0, 0, None, None, 0, 0)
