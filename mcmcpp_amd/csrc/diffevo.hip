@@ -23,7 +23,7 @@ namespace
 // for the rare walker where the answer is yes for some r, lane r walks the update that starts at draw r and the table
 // extra[r] goes to the candidate list.
 __global__ void __launch_bounds__(256)
-de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine128* jump_lo, const Affine128* jump_small, U128 inc, uint64_t threshold, int n)
+de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine128* jump_lo, const Affine128* jump_small, uint64_t threshold, int n)
 {
     __shared__ uint64_t sh_raw[4][64];
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
@@ -31,7 +31,6 @@ de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine1
     const U128 state = ctl->state;
     const Affine128 j_draw = jump_small[(lane < kDeRaw ? lane : kDeRaw - 1) + 1];
     const int waves = gridDim.x * 4;
-    (void)inc;
     for (int k = blockIdx.x * 4 + wib; k < n; k += waves)
     {
         const U128 base = apply(jump_lo[k & 255], apply(jump_hi[k >> 8], state));
@@ -282,7 +281,7 @@ public:
                     {
                         DeCtl* cur = d_ctl + (half_steps & 1);
                         DeCtl* nxt = d_ctl + ((half_steps + 1) & 1);
-                        hipLaunchKernelGGL(de_plan_kernel, dim3(plan_grid), dim3(256), 0, stream, cur, d_cand, d_jump_hi, d_jump_lo, d_jump_small, inc, threshold, n);
+                        hipLaunchKernelGGL(de_plan_kernel, dim3(plan_grid), dim3(256), 0, stream, cur, d_cand, d_jump_hi, d_jump_lo, d_jump_small, threshold, n);
                         a.ctl = cur;
                         a.ctl_next = nxt;
                         a.color = color;
@@ -382,17 +381,24 @@ public:
         if (count < 0 || (count > 0 && (!pos || !out))) return fail(MCMCPP_HIP_E_ARG, "calc_logp: bad arguments");
         if (count == 0) return MCMCPP_HIP_OK;
         HIP_TRY(hipSetDevice(device));
-        T *dp = nullptr, *dout = nullptr;
-        HIP_TRY(hipMalloc(&dp, sizeof(T) * (size_t)count * D));
-        HIP_TRY(hipMalloc(&dout, sizeof(T) * (size_t)count));
+        struct Scratch  // freed on every way out
+        {
+            T *rows = nullptr, *out = nullptr;
+            ~Scratch()
+            {
+                if (rows) (void)hipFree(rows);
+                if (out) (void)hipFree(out);
+            }
+        } scratch;
+        HIP_TRY(hipMalloc(&scratch.rows, sizeof(T) * (size_t)count * D));
+        HIP_TRY(hipMalloc(&scratch.out, sizeof(T) * (size_t)count));
+        T *dp = scratch.rows, *dout = scratch.out;
         HIP_TRY(hipMemcpyAsync(dp, pos, sizeof(T) * (size_t)count * D, hipMemcpyHostToDevice, stream));
         const long long per_block = (long long)(64 / lpw) * kWavesPerBlock;
         calc_fn(dp, dout, d_params, count, D, vec_ok, (unsigned)((count + per_block - 1) / per_block), stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, dout, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        hipFree(dp);
-        hipFree(dout);
         return MCMCPP_HIP_OK;
     }
 
