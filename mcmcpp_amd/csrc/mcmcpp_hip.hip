@@ -725,9 +725,18 @@ public:
         if (count < 0 || (count > 0 && (!pos || !out))) return fail(MCMCPP_HIP_E_ARG, "calc_logp: bad arguments");
         if (count == 0) return MCMCPP_HIP_OK;
         HIP_TRY(hipSetDevice(device));
-        T *dp = nullptr, *dout = nullptr;
-        HIP_TRY(hipMalloc(&dp, sizeof(T) * (size_t)count * D));
-        HIP_TRY(hipMalloc(&dout, sizeof(T) * (size_t)count));
+        struct Scratch  // freed on every way out
+        {
+            T *rows = nullptr, *out = nullptr;
+            ~Scratch()
+            {
+                if (rows) (void)hipFree(rows);
+                if (out) (void)hipFree(out);
+            }
+        } scratch;
+        HIP_TRY(hipMalloc(&scratch.rows, sizeof(T) * (size_t)count * D));
+        HIP_TRY(hipMalloc(&scratch.out, sizeof(T) * (size_t)count));
+        T *dp = scratch.rows, *dout = scratch.out;
         HIP_TRY(hipMemcpyAsync(dp, pos, sizeof(T) * (size_t)count * D, hipMemcpyHostToDevice, stream));
         const long long per_block = (long long)(64 / lpw) * kWavesPerBlock;
         const unsigned grid = (unsigned)((count + per_block - 1) / per_block);
@@ -735,8 +744,6 @@ public:
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(out, dout, sizeof(T) * (size_t)count, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        hipFree(dp);
-        hipFree(dout);
         return MCMCPP_HIP_OK;
     }
 
