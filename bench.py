@@ -17,8 +17,13 @@ The JSON line also carries
                 walker updates one launch performs: all 16 384 with the full-step kernel this workload takes,
                 8 192 with the half-step kernels) / the average launch duration measured with HIP events on
                 the launch stream around the replayed launches (mcmcpp_hip_last_run_timing)
-  cpu_baseline  the reference itself (oracle/_ref, kind "reference") or the oracle ("port") timed on this
-                host's cores on a bounded sample of the same workload (rank 0, N = 1 only)
+  cpu_baseline  the reference itself (oracle/_ref, kind "reference": built at the reference's own optimisation level,
+                oracle/Makefile) or the oracle ("port") timed on this host's cores on a bounded sample of the same
+                workload (rank 0, N = 1 only)
+  secondary     (N = 1) the other single-GPU configurations of BASELINE.json, each with its own roofline object:
+                C3 (65 536 x 32 Rosenbrock) and config 5's ensemble (131 072 x 64) on one GPU
+`--mode split` is BASELINE config 5 proper: one ensemble split over the ranks, launches and RCCL exchanges enqueued by
+libmcmcpp_hip.so itself (mcmcpp_hip_config.comm_*).
 """
 import argparse
 import json
@@ -66,12 +71,15 @@ def cpu_baseline(W, D, P, sample_steps):
     logp = orc.logp(pos)
     out = {}
     if po.reference_available():
-        # MCMC::EnsembleSampler of the reference, one thread, slicing so that only one step is stored
+        # MCMC::EnsembleSampler of the reference, one thread, slicing so that only one step is stored; the build at the
+        # reference's own optimisation level when it is there (-O3, contraction on: timing only, never parity)
+        timed = po.timed_reference_available()
         r = po.reference_run(W, D, po.CALC_DENSE_GAUSSIAN, P.ravel(), 0, pos, logp, 1, 1, slicing=sample_steps,
-                             want_chain=False)
+                             want_chain=False, timed_build=timed)
         out = dict(value=W * sample_steps / r["seconds"], unit="walker-steps/s", cores=1, kind="reference",
-                   sample="MCMC::EnsembleSampler<double, StretchMove> (reference, 1 thread): %d ensemble steps of "
-                          "the %dx%d workload, %.1f s" % (sample_steps, W, D, r["seconds"]))
+                   sample="MCMC::EnsembleSampler<double, StretchMove> (reference, 1 thread, %s): %d ensemble steps of "
+                          "the %dx%d workload, %.1f s" % ("-O3 -march=x86-64-v3 build" if timed else "-O2 contraction-off parity build",
+                                                          sample_steps, W, D, r["seconds"]))
     # the oracle on all cores (static walker partition): the fair analogue of ParallelEnsembleSampler
     orc.set_state(pos, logp)
     orc.run(1, interval=2, save_chain=False, mode=po.MODE_COUNTER, threads=cores)  # start the thread pool
@@ -89,76 +97,187 @@ def cpu_baseline(W, D, P, sample_steps):
     return out
 
 
+def source_digest():
+    """SHA-256 over the kernel and host sources of the library: what a counter measurement is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mcmcpp_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def counter_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed counter file (profiles/r*_pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate rocprofv3 --pmc passes of this very command) -- only if it was taken from the
+    sources this library was built from; otherwise null: a stale number is worse than none."""
+    import glob
+    digest = source_digest()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+        except ValueError:
+            continue
+        if pmc.get("source_sha256") == digest and pmc.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+            return pmc["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0):
+    """(2D+1)*8 read + (D+1)*8 written per walker update (+ D*8 when the step is stored), fp64, times the
+    walker updates one launch performs, over the average launch duration (HIP events on the launch stream)."""
+    bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
+    updates_per_launch = walker_steps / launches
+    bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * 8)
+    us_per_launch = gpu_ms * 1e3 / launches
+    achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates_per_launch,
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch}
+
+
+def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, reps):
+    """One of the other single-GPU configurations: `reps` runs of `batch` ensemble steps (nothing stored), with its roofline."""
+    s = capi.HipSampler(W, D, calc, params, seed=0, device=device)
+    pos = workloads.init_positions(W, D, salt=0)
+    s.set_state(pos, s.calc_logp(pos))
+    s.run(1, interval=batch, save_chain=False)
+    accepted = 0
+    gpu_ms, launches = 0.0, 0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _, acc = s.run(1, interval=batch, save_chain=False)
+        accepted += int(acc.sum())
+        ms, nl = s.last_run_timing()
+        gpu_ms += ms
+        launches += nl
+    dt = time.perf_counter() - t0
+    ws = float(W) * batch * reps
+    s.close()
+    return {"workload": name, "walkers": W, "dims": D, "value": ws / dt, "unit": "walker-steps/s",
+            "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws,
+            "roofline": roofline_of(W, D, ws, launches, gpu_ms, kernel)}
+
+
 def bench_split(args, rank, local_rank, world, dist, torch, capi):
-    """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling."""
-    from mcmcpp_amd import distributed as md
+    """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling.
+    Every rank owns one handle with an RCCL communicator: mcmcpp_hip_run enqueues the step launches and the exchanges."""
     from mcmcpp_amd import workloads
-    if dist is None:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29655")
-        with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-            dist.barrier()
-    W, D = 131072, 64
+    W, D = args.split_walkers, 64
     steps_per = 50
-    dev = "cuda:%d" % local_rank
-    ens = md.SplitEnsemble(W, D, lambda b, c: md.HipShardBackend(W, D, capi.CALC_ISO_GAUSSIAN, None, 0, 0, capi.F64, b, c, dev))
+    with _StdoutToStderr():  # (RCCL's banner)
+        if world > 1:
+            box = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            cid = box[0]
+        else:
+            cid = capi.comm_unique_id()
+        ens = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, device=local_rank, comm_world=world, comm_rank=rank,
+                              comm_id=cid)
     pos = workloads.init_positions(W, D, salt=0)
     logp = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank).calc_logp(pos)
     ens.set_state(pos, logp)
     for _ in range(args.warmup):
         ens.run(1, interval=steps_per, save_chain=False)
-    dist.barrier()
-    torch.cuda.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    accepted, gpu_ms, launches, enq_ms, xchg_us = 0, 0.0, 0, 0.0, 0.0
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ens.run(1, interval=steps_per, save_chain=False)
-    dist.barrier()
-    torch.cuda.synchronize()
+        _, acc = ens.run(1, interval=steps_per, save_chain=False)
+        accepted += int(acc.sum())  # (ensemble-wide counts: all-reduced by the library)
+        ms, nl = ens.last_run_timing()
+        gpu_ms += ms
+        launches += nl
+        e, _, x = ens.last_run_host_timing()
+        enq_ms += e
+        xchg_us += x
+    barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    _, _, nacc = ens.gather_state()
-    accepted = int(nacc.sum().item())
-    total = float(W) * steps_per * (args.steps + args.warmup)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_steps = steps_per * args.steps
+    total = float(W) * n_steps
     if rank == 0:
-        exchanged = (W // 2) * D * 8 * (world - 1) / world  # bytes each rank receives per half-step
-        print(json.dumps({
+        per_step_launches = launches / n_steps  # 1: one exchange per ensemble step; 2: one per half-step
+        recv = W * D * 8 * (world - 1) / world  # position bytes each rank receives per ensemble step
+        xchg = xchg_us / args.steps
+        # what one rank updates per launch: its slice of one colour (half-step kernels) or of both (full-step kernels)
+        updates = float(W) / world / (2 if per_step_launches > 1.5 else 1)
+        kernel = ("stretch_full_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>" if per_step_launches < 1.5 else
+                  "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>")
+        step_us = gpu_ms * 1e3 / n_steps  # GPU time of one ensemble step on the launch stream: kernels + exchange
+        kern_us = max(step_us - xchg, 1e-9) / per_step_launches
+        bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
+        achieved = updates * bytes_per_update / (kern_us * 1e-6) / 1e9
+        line = {
             "metric": "walker-steps/sec + acceptance rate, 131072 walkers x 64 dims split over the GPUs",
-            "value": float(W) * steps_per * args.steps / elapsed, "unit": "walker-steps/s", "n_gpus": world,
+            "value": total / elapsed, "unit": "walker-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "acceptance_rate": accepted / total,
-            "config": {"workload": "C5: one 131072x64 isotropic-Gaussian ensemble split over %d GPU(s), RCCL all-gather "
-                                   "of the updated half-ensemble slice after every half-step; one step = %d ensemble steps"
-                                   % (world, steps_per), "walkers": W, "dims": D},
-            "allgather": {"bytes_received_per_rank_per_half_step": exchanged,
-                          "half_steps": 2 * steps_per * args.steps}}), flush=True)
-    dist.destroy_process_group()
+            "config": {"workload": "C5: one %dx%d isotropic-Gaussian ensemble split over %d GPU(s); launches and RCCL all-gathers "
+                                   "enqueued by libmcmcpp_hip.so (%s); one step = %d ensemble steps"
+                                   % (W, D, world, "one exchange per ensemble step, full-step kernels on the rank's slice"
+                                      if per_step_launches < 1.5 else "one exchange per half-step", steps_per),
+                       "walkers": W, "dims": D, "ranks": world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates,
+                         "algorithmic_bytes_per_launch": updates * bytes_per_update, "avg_launch_us": kern_us,
+                         "note": "per rank; launch time = (stream time of a step - sampled exchange time) / launches per step"},
+            "allgather": {"bytes_received_per_rank_per_step": recv, "exchange_us_per_step": xchg,
+                          "gb_per_s_per_rank": (recv / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,
+                          "gb_per_s_per_link": (recv / (world - 1) / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,
+                          "link_peak_gb_per_s": 153.0,
+                          "note": "exchange time = HIP events around a sample of exchanges on the launch stream; a single rank "
+                                  "moves nothing (rates null)"},
+            "host": {"enqueue_us_per_step": enq_ms * 1e3 / n_steps, "gpu_us_per_step": step_us,
+                     "note": "time the host thread spends enqueueing one ensemble step (launches + exchange calls) against the "
+                             "GPU time of that step: the host must stay below it"},
+        }
+        print(json.dumps(line), flush=True)
+    ens.close()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed bench steps (default 500: about 6 s of stepping, so that the timed region dominates the run "
+                         "and a GPU-busy sampler sees it; --mode split: 20)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=2000, help="ensemble steps per bench step (SURVEY.md 8d: C2 runs 2 000 steps)")
     ap.add_argument("--interval", type=int, default=100, help="slicing interval (one stored step per interval)")
     ap.add_argument("--walkers", type=int, default=16384)
     ap.add_argument("--dims", type=int, default=32)
-    ap.add_argument("--cpu-sample-steps", type=int, default=1000,
+    ap.add_argument("--cpu-sample-steps", type=int, default=2000,
                     help="ensemble steps of the workload timed on the CPU (about 20 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-ensemble secondary measurements")
     ap.add_argument("--no-chain", action="store_true", help="experiments only: store nothing")
+    ap.add_argument("--pageable-chain", action="store_true", help="experiments only: stored steps into pageable host memory")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
     ap.add_argument("--mode", default="chains", choices=["chains", "split"],
                     help="chains (default, the headline): one independent C2 chain per GPU; split: BASELINE config 5, "
-                         "one 131072x64 ensemble split over the GPUs with an RCCL all-gather per half-step")
+                         "one 131072x64 ensemble split over the GPUs, exchanged over RCCL by the library")
+    ap.add_argument("--split-walkers", type=int, default=131072,
+                    help="--mode split: walkers of the ensemble (16384 on one GPU = what one rank of the 8-GPU job updates)")
     ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
                     help="experiments only: the headline workload is the dense (correlated) Gaussian")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.mode == "split" else 500
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -202,9 +321,16 @@ def main():
     pos = workloads.init_positions(W, D, salt=rank)
     sampler.set_state(pos, sampler.calc_logp(pos))
 
-    # the stored steps land in host memory that already exists, like a block of the facade's Chain (allocated
-    # once, filled as the run proceeds); the download itself is inside the timed region
-    chain_block = None if args.no_chain else np.zeros((n_saved, W, D))
+    # The stored steps land in host memory that already exists, like a block of the facade's Chain: pinned host memory
+    # handed out by the library (include/MCMCpp/Device/SamplerCore.h allocates its blocks the same way), so the step
+    # launches forward stored steps straight into it.  The transfer is inside the timed region either way.
+    if args.no_chain:
+        chain_block = None
+    elif args.pageable_chain:
+        chain_block = np.zeros((n_saved, W, D))
+    else:
+        chain_block = capi.pinned_empty((n_saved, W, D))
+        chain_block[:] = 0.0
 
     def bench_step():
         return sampler.run(n_saved, interval=args.interval, save_chain=not args.no_chain,
@@ -239,25 +365,22 @@ def main():
         elapsed, walker_steps, [float(accepted), gpu_ms, float(launches)], device=reduce_device)
 
     if rank == 0:
-        bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8          # 784 B at D = 32, fp64
-        saved_fraction = 1.0 / args.interval
+        saved_fraction = 0.0 if args.no_chain else 1.0 / args.interval
         # walker updates one launch performs: W/2 for the half-step kernels, W when the library steps with one
         # launch per ensemble step (full_step_kernel.hpp)
-        updates_per_launch = walker_steps / launches
-        full_step = updates_per_launch > 0.75 * W
+        full_step = walker_steps / launches > 0.75 * W
         kernel = ("stretch_full_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>" if full_step else
                   "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16, P=2>")
-        bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * 8)
-        us_per_launch = gpu_ms * 1e3 / launches
-        achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-        # HBM bytes per launch from the PMC counters: collected by a separate rocprofv3 --pmc run of this very
-        # command (counters cannot be read from inside the process) and committed with its provenance
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if args.calc == "dense" and (W, D) == (16384, 32) and os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
-            if pmc.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
-                traffic = pmc["hbm_bytes_per_launch"]
+        roof = roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction)
+        # HBM bytes per launch from the PMC counters: collected by separate rocprofv3 --pmc passes of this very command
+        # (counters cannot be read from inside the process), committed with the digest of the sources they were taken
+        # from, and reported only while that digest is the one this library was built from
+        traffic, traffic_file = counter_traffic(kernel) if args.calc == "dense" and (W, D) == (16384, 32) else (None, None)
+        roof["traffic"] = traffic
+        roof["traffic_source"] = (traffic_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
+                                  "the gfx950 correction; taken from the sources this library was built from)") if traffic else None
+        roof["note"] = ("avg launch duration = HIP-event time on the launch stream over the graph-replayed step launches / launches; "
+                        "it includes the ~1.5 us dependent-launch boundary")
         line = {
             "metric": "walker-steps/sec + acceptance rate, 16384 walkers x 32 dims, 1/2/4/8 GPU",
             "value": walker_steps / elapsed,
@@ -278,20 +401,22 @@ def main():
                                                        "one independent chain per GPU (seed = rank)" if world > 1
                                                        else "one chain"),
                        "walkers": W, "dims": D, "ensemble_steps_per_step": args.batch,
-                       "slicing_interval": args.interval, "chains": world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel,
-                         "walker_updates_per_launch": updates_per_launch,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": us_per_launch,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
-                                           "passes; FETCH_SIZE doubled per the gfx950 correction)" if traffic else None,
-                         "note": "avg launch duration = HIP-event time on the launch stream over the graph-replayed "
-                                 "step launches / launches; it includes the ~1.5 us dependent-launch boundary"},
+                       "slicing_interval": args.interval, "chains": world,
+                       "chain_memory": "none" if args.no_chain else ("pageable" if args.pageable_chain else "pinned block from the library")},
+            "roofline": roof,
         }
         if args.calc != "dense":
             line["config"]["workload"] += " [EXPERIMENT: calculator = %s, not the headline workload]" % args.calc
+        if world == 1 and not args.no_secondary and args.calc == "dense":
+            sampler.close()
+            line["secondary"] = [
+                secondary_config(capi, workloads, local_rank, "C3: 65536 walkers x 32 dims, Rosenbrock log-posterior, StretchMove, fp64; "
+                                 "runs of 1000 ensemble steps, nothing stored", 65536, 32, capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05],
+                                 "stretch_half_step_kernel<double, RosenbrockFn, EPL=2, LPW=16>", 1000, 4),
+                secondary_config(capi, workloads, local_rank, "C5's ensemble on ONE GPU: 131072 walkers x 64 dims, isotropic Gaussian, "
+                                 "StretchMove, fp64; runs of 500 ensemble steps, nothing stored", 131072, 64, capi.CALC_ISO_GAUSSIAN, None,
+                                 "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>", 500, 4),
+            ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)
         print(json.dumps(line), flush=True)

@@ -43,8 +43,9 @@ public:
     typedef ChainStepIterator<ParamType> StepIterator;
 
     /// maxSize: byte budget for stored steps (the reference's maxChainSizeBytes).  At least one step is always storable.
-    Chain(int numWalkers, int numParams, unsigned long long maxSize, unsigned long long blockBytes = Detail::DefaultBlockBytes)
-        : walkerCount(numWalkers), cellsPerWalker(numParams),
+    Chain(int numWalkers, int numParams, unsigned long long maxSize, unsigned long long blockBytes = Detail::DefaultBlockBytes,
+          const Detail::BlockMemory& memory = Detail::BlockMemory())
+        : blockMemory(memory), walkerCount(numWalkers), cellsPerWalker(numParams),
           cellsPerStep(static_cast<std::int64_t>(numWalkers) * numParams), stepCount(0)
     {
         const unsigned long long stepBytes = static_cast<unsigned long long>(cellsPerStep) * sizeof(ParamType);
@@ -162,7 +163,7 @@ private:
             const std::int64_t lo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
             if (lo + want > maxSteps) want = maxSteps - lo;
             if (want < 1) return nullptr;
-            ChainBlock<ParamType>* nb = new ChainBlock<ParamType>(want, cellsPerStep);
+            ChainBlock<ParamType>* nb = new ChainBlock<ParamType>(want, cellsPerStep, blockMemory);
             if (!nb->valid())
             {
                 delete nb;
@@ -174,6 +175,7 @@ private:
     }
 
     std::vector<ChainBlock<ParamType>*> blocks;
+    Detail::BlockMemory blockMemory;
     int walkerCount;
     int cellsPerWalker;
     std::int64_t cellsPerStep;

@@ -22,22 +22,42 @@ namespace Detail
 {
 /// Default slab size; the number of steps per block follows from it and the ensemble size.
 static const unsigned long long DefaultBlockBytes = 256ULL << 20;
+
+/// Where a block's memory comes from.  The default is the heap (64-byte aligned like the reference's autoAlignedAlloc,
+/// Utility/Misc.h:77-102); the MI355X samplers hand out pinned host memory (mcmcpp_hip_host_alloc) so that the step
+/// launches write stored steps straight into the block.  A failed `obtain` falls back to the heap.
+struct BlockMemory
+{
+    void* (*obtain)(unsigned long long bytes);
+    void (*release)(void*);
+    BlockMemory() : obtain(nullptr), release(nullptr) {}
+    BlockMemory(void* (*get)(unsigned long long), void (*put)(void*)) : obtain(get), release(put) {}
+};
 }
 
 template <class ParamType>
 class ChainBlock
 {
 public:
-    ChainBlock(std::int64_t stepsInBlock, std::int64_t cellsInStep)
-        : capacitySteps(stepsInBlock), cellsPerStep(cellsInStep), usedSteps(0), cells(nullptr)
+    ChainBlock(std::int64_t stepsInBlock, std::int64_t cellsInStep, const Detail::BlockMemory& mem = Detail::BlockMemory())
+        : capacitySteps(stepsInBlock), cellsPerStep(cellsInStep), usedSteps(0), cells(nullptr), releaseFn(nullptr)
     {
         const std::size_t bytes = static_cast<std::size_t>(capacitySteps) * static_cast<std::size_t>(cellsPerStep) * sizeof(ParamType);
-        // 64-byte alignment like the reference's autoAlignedAlloc (Utility/Misc.h:77-102)
         void* p = nullptr;
-        if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0) p = nullptr;
+        if (mem.obtain && mem.release) p = mem.obtain(bytes ? bytes : 64);
+        if (p)
+            releaseFn = mem.release;
+        else if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0)
+            p = nullptr;
         cells = static_cast<ParamType*>(p);
     }
-    ~ChainBlock() { std::free(cells); }
+    ~ChainBlock()
+    {
+        if (releaseFn)
+            releaseFn(cells);
+        else
+            std::free(cells);
+    }
     ChainBlock(const ChainBlock&) = delete;
     ChainBlock& operator=(const ChainBlock&) = delete;
 
@@ -54,6 +74,7 @@ private:
     std::int64_t cellsPerStep;
     std::int64_t usedSteps;
     ParamType* cells;
+    void (*releaseFn)(void*);
 };
 
 }  // namespace Chain

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "../../mcmcpp_hip.h"
 
@@ -34,6 +35,37 @@ struct HipDtype<float>
     static const int value = MCMCPP_HIP_F32;
 };
 
+/// Which GPUs a sampler runs on.  One device (the default: the process's current device) steps the whole ensemble; several
+/// split ONE ensemble between them -- every device keeps the full replica of the positions, updates its slice of both
+/// halves and exchanges the updated rows over RCCL once per ensemble step (the role of ParallelEnsembleSampler's
+/// threadCount workers and barrier controller, /root/reference/MCMCpp/ParallelEnsembleSampler.h:119-120,285-291).
+/// Results do not depend on the placement.  The reference's constructors have no such argument, so unchanged user code
+/// selects a placement through the environment: MCMCPP_DEVICES="0,1,2,3" (HIP device ordinals).
+struct Placement
+{
+    std::vector<int> devices;  ///< HIP device ordinals; empty = the current device
+    bool splitEnsemble;        ///< true: go through the communicator even with one device (tests of the split path)
+    Placement() : splitEnsemble(false) {}
+    explicit Placement(int device) : devices(1, device), splitEnsemble(false) {}
+    explicit Placement(const std::vector<int>& list) : devices(list), splitEnsemble(false) {}
+    static Placement fromEnvironment()
+    {
+        Placement p;
+        const char* v = std::getenv("MCMCPP_DEVICES");
+        while (v && *v)
+        {
+            char* end = nullptr;
+            const long d = std::strtol(v, &end, 10);
+            if (end == v) break;
+            p.devices.push_back(static_cast<int>(d));
+            v = (*end == ',') ? end + 1 : end;
+        }
+        return p;
+    }
+    int count() const { return devices.empty() ? 1 : static_cast<int>(devices.size()); }
+    int device(int k) const { return devices.empty() ? -1 : devices[static_cast<std::size_t>(k)]; }
+};
+
 class HipHandle
 {
 public:
@@ -44,10 +76,11 @@ public:
     }
     HipHandle(const HipHandle&) = delete;
     HipHandle& operator=(const HipHandle&) = delete;
+    HipHandle(HipHandle&& other) noexcept : handle(other.handle) { other.handle = nullptr; }
 
     void create(const mcmcpp_hip_config& cfg)
     {
-        const int rc = mcmcpp_hip_create(&cfg, &handle);
+        const int rc = mcmcpp_hip_create(&cfg, &handle);  // (the message of a failed create is kept per thread)
         if (rc != MCMCPP_HIP_OK) die("mcmcpp_hip_create", rc, mcmcpp_hip_last_error(nullptr));
     }
     /// Abort with the library's message unless rc is MCMCPP_HIP_OK.

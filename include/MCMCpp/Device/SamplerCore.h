@@ -7,7 +7,8 @@
  *     step per walker                                                       (EnsembleSampler.h:220-230, Walker/Walker.h:76,162-170)
  *   - runMCMC(n): n stored steps; with sub-sampling interval k every stored step is preceded by k-1
  *     unstored ensemble steps; returns false once the chain's byte budget is exhausted   (EnsembleSampler.h:284-310)
- *   - the PostStepAction runs once after every ensemble step                 (EnsembleSampler.h:356-359)
+ *   - the PostStepAction runs once per ensemble step and sees the chain without the step being made
+ *                                                                            (EnsembleSampler.h:291-293,356-359)
  *   - reset() forgets chain and counters, keeps positions and the random stream          (EnsembleSampler.h:312-322)
  * Not kept: the parallel sampler's run-to-run non-determinism (ParallelEnsembleSampler.h:71-76) and its
  * sub-sampling defect (Threading/RedBlkCtrlerSpinLock.h:297-300) -- both samplers follow the sequential
@@ -18,6 +19,9 @@
 
 #include <cassert>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <vector>
 
 #include "../Chain/Chain.h"
@@ -43,9 +47,10 @@ public:
                   "the PostStepAction needs 'void performAction(const StepItt& start, const StepItt& end)'");
 
     SamplerCore(int randSeed, long long stream, int numWalker, int numParameter, const Mover& move,
-                unsigned long long maxChainSizeBytes, PostStepAction* stepAct)
-        : stepAction(stepAct), markovChain(numWalker, numParameter, maxChainSizeBytes), moveProposer(move),
-          numParams(numParameter), numWalkers(numWalker), initialPlacementCounted(false)
+                unsigned long long maxChainSizeBytes, PostStepAction* stepAct, const Placement& where = Placement::fromEnvironment())
+        : stepAction(stepAct),
+          markovChain(numWalker, numParameter, maxChainSizeBytes, Chain::Detail::DefaultBlockBytes, Chain::Detail::BlockMemory(&pinnedObtain, &pinnedRelease)),
+          moveProposer(move), numParams(numParameter), numWalkers(numWalker), initialPlacementCounted(false)
     {
         assert(numWalkers % 2 == 0);             // EnsembleSampler.h:207
         assert(numWalkers > (2 * numParams));    // EnsembleSampler.h:208
@@ -60,16 +65,42 @@ public:
         cfg.calc_params_len = moveProposer.getCalculator().hipParamCount();
         cfg.seed = static_cast<std::uint64_t>(static_cast<long long>(randSeed));  // sign-extends like MultiSampler::setPrng
         cfg.stream = static_cast<std::uint64_t>(stream);
-        cfg.device = -1;
         cfg.gw_alpha_num = Mover::DistributionType::Numerator;
         cfg.gw_alpha_den = Mover::DistributionType::Denominator;
         cfg.mover = Mover::HipMoverId;
-        device.create(cfg);
+        const int G = where.count();
+        ranks.resize(static_cast<std::size_t>(G));
+        if (G == 1 && !where.splitEnsemble)
+        {
+            cfg.device = where.device(0);
+            ranks[0].create(cfg);
+            return;
+        }
+        // One ensemble split over G devices: one handle per device, all ranks of one RCCL communicator.  The communicator's
+        // rendezvous blocks until every rank has joined, so the handles are created concurrently.
+        unsigned char commId[MCMCPP_HIP_COMM_ID_BYTES];
+        const int idrc = mcmcpp_hip_comm_unique_id(commId);
+        if (idrc != MCMCPP_HIP_OK)
+        {
+            std::fprintf(stderr, "MCMCpp (MI355X): mcmcpp_hip_comm_unique_id failed with code %d: %s\n", idrc, mcmcpp_hip_last_error(nullptr));
+            std::abort();
+        }
+        std::vector<std::thread> joiners;
+        for (int r = 0; r < G; ++r)
+            joiners.push_back(std::thread([this, cfg, r, G, &where, &commId]() {
+                mcmcpp_hip_config mine = cfg;
+                mine.device = where.device(r);
+                mine.comm_world = G;
+                mine.comm_rank = r;
+                mine.comm_id = commId;
+                ranks[static_cast<std::size_t>(r)].create(mine);
+            }));
+        for (std::thread& t : joiners) t.join();
     }
 
     void setInitialWalkerPos(ParamType* positions, ParamType* auxValues)
     {
-        device.check("mcmcpp_hip_set_state", mcmcpp_hip_set_state(device.get(), positions, auxValues));
+        for (HipHandle& h : ranks) h.check("mcmcpp_hip_set_state", mcmcpp_hip_set_state(h.get(), positions, auxValues));
         for (int w = 0; w < numWalkers; ++w) markovChain.storeWalker(w, positions + static_cast<std::size_t>(w) * numParams);
         markovChain.incrementChainStep();
         initialPlacementCounted = true;
@@ -80,7 +111,7 @@ public:
         std::int64_t room = 0;
         ParamType* dst = markovChain.stepsContiguousFrom(&room);
         if (!dst || room < 1) return;
-        device.check("mcmcpp_hip_get_state", mcmcpp_hip_get_state(device.get(), dst, nullptr, nullptr));
+        ranks[0].check("mcmcpp_hip_get_state", mcmcpp_hip_get_state(ranks[0].get(), dst, nullptr, nullptr));
         markovChain.commitSteps(1);
     }
 
@@ -93,22 +124,33 @@ public:
             std::int64_t room = 0;
             ParamType* dst = markovChain.stepsContiguousFrom(&room);
             if (!dst || room < 1) return false;
-            // a PostStepAction sees the chain after every ensemble step, so it forces one step per launch batch
-            std::int64_t now = (stepAction != nullptr) ? 1 : (left < room ? left : room);
-            if (stepAction != nullptr && interval > 1)
+            const std::int64_t now = left < room ? left : room;
+            if (stepAction == nullptr && ranks.size() == 1)
             {
-                // interval-1 unstored steps, the action after each, then the stored one
-                for (int j = 1; j < interval; ++j)
-                {
-                    device.check("mcmcpp_hip_run", mcmcpp_hip_run(device.get(), 1, 1, nullptr, nullptr));
-                    stepAction->performAction(markovChain.getStepIteratorBegin(), markovChain.getStepIteratorEnd());
-                }
-                device.check("mcmcpp_hip_run", mcmcpp_hip_run(device.get(), 1, 1, dst, nullptr));
+                ranks[0].check("mcmcpp_hip_run", mcmcpp_hip_run(ranks[0].get(), now, interval, dst, nullptr));
+                markovChain.commitSteps(now);
             }
             else
-                device.check("mcmcpp_hip_run", mcmcpp_hip_run(device.get(), now, interval, dst, nullptr));
-            markovChain.commitSteps(now);
-            if (stepAction != nullptr) stepAction->performAction(markovChain.getStepIteratorBegin(), markovChain.getStepIteratorEnd());
+            {
+                // Every rank steps on its handle's worker thread (a split ensemble's ranks meet in the exchanges), rank 0
+                // receives the stored steps.  The PostStepAction runs here, beside the device: once per ensemble step, and
+                // -- as in the reference, which calls it before the chain moves on to the next step
+                // (EnsembleSampler.h:291-293,356-359) -- it sees the chain WITHOUT the step being made.  Nothing it can
+                // observe changes during the interval-1 unstored steps, so their calls follow each other directly.
+                for (std::size_t r = 0; r < ranks.size(); ++r)
+                    ranks[r].check("mcmcpp_hip_run_async", mcmcpp_hip_run_async(ranks[r].get(), now, interval, r == 0 ? dst : nullptr, nullptr));
+                for (std::int64_t k = 0; k < now; ++k)
+                {
+                    if (stepAction != nullptr)
+                    {
+                        ranks[0].check("mcmcpp_hip_wait_stored", mcmcpp_hip_wait_stored(ranks[0].get(), k + 1));
+                        for (int j = 0; j < interval; ++j) stepAction->performAction(markovChain.getStepIteratorBegin(), markovChain.getStepIteratorEnd());
+                        markovChain.commitSteps(1);
+                    }
+                }
+                for (HipHandle& h : ranks) h.check("mcmcpp_hip_run_wait", mcmcpp_hip_run_wait(h.get()));
+                if (stepAction == nullptr) markovChain.commitSteps(now);
+            }
             left -= now;
             if (markovChain.remainingSteps() == 0) return false;  // budget reached with this step (EnsembleSampler.h:293,306)
         }
@@ -118,20 +160,25 @@ public:
     void reset()
     {
         markovChain.resetChain();
-        device.check("mcmcpp_hip_reset_counters", mcmcpp_hip_reset_counters(device.get()));
+        for (HipHandle& h : ranks) h.check("mcmcpp_hip_reset_counters", mcmcpp_hip_reset_counters(h.get()));
         initialPlacementCounted = false;
     }
 
     unsigned long long acceptedSteps()
     {
-        std::uint64_t acc = 0;
-        device.check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(device.get(), &acc, nullptr, nullptr, nullptr));
-        return acc + (initialPlacementCounted ? static_cast<unsigned long long>(numWalkers) : 0ULL);
+        unsigned long long total = 0;
+        for (HipHandle& h : ranks)  // (a rank counts the walkers it updates)
+        {
+            std::uint64_t acc = 0;
+            h.check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(h.get(), &acc, nullptr, nullptr, nullptr));
+            total += acc;
+        }
+        return total + (initialPlacementCounted ? static_cast<unsigned long long>(numWalkers) : 0ULL);
     }
     unsigned long long totalSteps()
     {
         std::uint64_t steps = 0;
-        device.check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(device.get(), nullptr, &steps, nullptr, nullptr));
+        ranks[0].check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(ranks[0].get(), nullptr, &steps, nullptr, nullptr));
         return static_cast<unsigned long long>(numWalkers) * (steps + (initialPlacementCounted ? 1ULL : 0ULL));
     }
     ParamType acceptanceFraction()
@@ -142,21 +189,34 @@ public:
     /// Walker positions, log-posteriors and per-walker accepted counts as they stand on the device (any may be null).
     void currentState(ParamType* positions, ParamType* logp, std::uint32_t* nAccept)
     {
-        device.check("mcmcpp_hip_get_state", mcmcpp_hip_get_state(device.get(), positions, logp, nAccept));
+        ranks[0].check("mcmcpp_hip_get_state", mcmcpp_hip_get_state(ranks[0].get(), positions, logp, nAccept));
     }
-    /// Parity diagnostics of the device path (see include/mcmcpp_hip.h).
+    /// Parity diagnostics of the device path (see include/mcmcpp_hip.h), summed over the devices.
     void diagnostics(std::uint64_t* nearTies, std::uint64_t* redraws)
     {
-        device.check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(device.get(), nullptr, nullptr, nearTies, redraws));
+        std::uint64_t t = 0, r = 0;
+        for (HipHandle& h : ranks)
+        {
+            std::uint64_t ht = 0, hr = 0;
+            h.check("mcmcpp_hip_get_counters", mcmcpp_hip_get_counters(h.get(), nullptr, nullptr, &ht, &hr));
+            t += ht;
+            r += hr;
+        }
+        if (nearTies) *nearTies = t;
+        if (redraws) *redraws = r;
     }
+    int deviceCount() const { return static_cast<int>(ranks.size()); }
 
     ChainType& chain() { return markovChain; }
 
 protected:
+    static void* pinnedObtain(unsigned long long bytes) { return mcmcpp_hip_host_alloc(bytes); }
+    static void pinnedRelease(void* p) { mcmcpp_hip_host_free(p); }
+
     PostStepAction* stepAction;
     ChainType markovChain;
     Mover moveProposer;
-    HipHandle device;
+    std::vector<HipHandle> ranks;  ///< one handle per device of the placement
     int numParams;
     int numWalkers;
     bool initialPlacementCounted;

@@ -8,7 +8,9 @@
  * grid -- one kernel launch per half-step, the launch boundary being the reference's mid/end-step barrier
  * (Threading/RedBlkCtrlerSpinLock.h:240-322) -- and every walker addresses the single stream-0 sequence of
  * the sequential sampler, so the result is reproducible and equal to EnsembleSampler's.
- * threadCount and UseSpinLocks are accepted for source compatibility and do not affect the device path.
+ * threadCount and UseSpinLocks are accepted for source compatibility and do not affect the device path; which GPUs
+ * the sampler uses is a Device::Placement (constructor overload, or MCMCPP_DEVICES in the environment for unchanged
+ * user code): several devices split the one ensemble between them (Device/SamplerCore.h).
  * Every public method takes the sampler mutex, as in the reference.
  */
 #ifndef MCMCPP_PARALLELENSEMBLESAMPLER_H
@@ -36,6 +38,14 @@ public:
     ParallelEnsembleSampler(int randSeed, int threadCount, int numWalker, int numParameter, const Mover& move,
                             unsigned long long maxChainSizeBytes = 2147483648ULL, PostStepAction* stepAct = nullptr)
         : Core(randSeed, 0, numWalker, numParameter, move, maxChainSizeBytes, stepAct), numThreads(threadCount), subSamplingInterval(1)
+    {
+        assert(threadCount > 0);
+    }
+    /// The same on an explicit set of GPUs (not in the reference, whose only placement argument is threadCount): several
+    /// devices split the ONE ensemble between them, exchanging the updated rows over RCCL once per ensemble step.
+    ParallelEnsembleSampler(int randSeed, int threadCount, int numWalker, int numParameter, const Mover& move, unsigned long long maxChainSizeBytes,
+                            PostStepAction* stepAct, const Device::Placement& where)
+        : Core(randSeed, 0, numWalker, numParameter, move, maxChainSizeBytes, stepAct, where), numThreads(threadCount), subSamplingInterval(1)
     {
         assert(threadCount > 0);
     }
@@ -117,6 +127,7 @@ public:
     }
     using Core::currentState;
     using Core::diagnostics;
+    using Core::deviceCount;
 
 private:
     std::mutex samplerMutex;

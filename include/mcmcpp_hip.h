@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCMCPP_HIP_ABI_VERSION 1
+#define MCMCPP_HIP_ABI_VERSION 2
 
 /* return codes */
 enum {
@@ -39,7 +39,8 @@ enum {
     MCMCPP_HIP_E_NO_DEVICE = 3,   /* no gfx950 device / device ordinal out of range */
     MCMCPP_HIP_E_UNSUPPORTED = 4, /* configuration outside what the kernels were built for */
     MCMCPP_HIP_E_STATE = 5,       /* run/get before set_state */
-    MCMCPP_HIP_E_NOMEM = 6
+    MCMCPP_HIP_E_NOMEM = 6,
+    MCMCPP_HIP_E_COMM = 7         /* the collective library (RCCL) is missing or one of its calls failed */
 };
 
 /* ParamType of the reference templates */
@@ -85,11 +86,29 @@ typedef struct mcmcpp_hip_config {
     int32_t gw_alpha_den;
     void* device_positions;  /* optional caller-owned DEVICE buffer of W*D elements used in place of an
                                 internal one (e.g. memory registered with a collective library) */
-    void* hip_stream;        /* hipStream_t to launch on when MCMCPP_HIP_FLAG_CALLER_STREAM is set (NULL is then the
-                                legacy default stream); otherwise ignored and the handle owns a private stream */
+    void* hip_stream;        /* hipStream_t to launch on when MCMCPP_HIP_FLAG_CALLER_STREAM is set; otherwise ignored and the
+                                handle owns a private non-blocking stream.  NULL (the legacy default stream) is accepted,
+                                but HIP cannot capture graphs on it: such a handle steps with plain launches */
     uint32_t flags;          /* MCMCPP_HIP_FLAG_* */
     uint32_t mover;          /* MCMCPP_HIP_MOVER_*: which Mover::updateWalker the kernels implement; 0 = StretchMove */
+    /* One ensemble split over comm_world GPUs (one handle per GPU; stands in for ParallelEnsembleSampler's threadCount
+     * workers, ParallelEnsembleSampler.h:119-120,285-291, and the red/black controller's two barriers per step,
+     * Threading/RedBlkCtrlerSpinLock.h:240-322).  comm_world >= 1 makes this handle rank comm_rank of an RCCL
+     * communicator (created from comm_id, or taken from comm) and lets mcmcpp_hip_run step the split ensemble: the
+     * handle's shard must be the rank's slice, [comm_rank * (W/2) / comm_world, + (W/2) / comm_world) -- shard_count = 0
+     * selects exactly that -- and W/2 must divide by comm_world.  Every rank calls set_state / run / get_state with the
+     * same arguments; the exchanges (ncclAllGather of the updated rows, once per ensemble step) are enqueued on the
+     * launch stream by run itself, with no host round trip in between.  0 = no communicator. */
+    int32_t comm_world;
+    int32_t comm_rank;
+    const void* comm_id;     /* MCMCPP_HIP_COMM_ID_BYTES bytes made by mcmcpp_hip_comm_unique_id on one rank and handed to
+                                all ranks by the caller's own means (file, MPI, torch.distributed ...), or NULL */
+    void* comm;              /* or: an existing ncclComm_t of comm_world ranks on this handle's device (borrowed) */
 } mcmcpp_hip_config;
+
+#define MCMCPP_HIP_COMM_ID_BYTES 128
+/* ncclGetUniqueId: the rendezvous token of a new communicator (call on one rank). */
+int mcmcpp_hip_comm_unique_id(void* id_out);
 
 /* Movers (reference MCMCpp/Movers/).  DIFFERENTIAL_EVOLUTION = Mover::DifferentialEvolution
  * (Movers/DifferentialEvolution.h:80-112) with the gamma and jitter bounds its constructors set -- the samplers work on
@@ -132,6 +151,21 @@ int mcmcpp_hip_set_state(mcmcpp_hip_sampler* h, const void* positions, const voi
 int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out,
                    uint32_t* accepted_per_step);
 
+/* The same run on a worker thread owned by the handle, so that the caller can look at stored steps while the device keeps
+ * stepping -- what a PostStepAction needs (EnsembleSampler.h:356-359: called after every ensemble step with the chain as it
+ * stands).  run_async returns at once; wait_stored(count) returns when the first `count` stored steps of this run are
+ * complete in chain_out (or with the run's error code if it ended before that); run_wait joins the worker and returns what
+ * mcmcpp_hip_run would have returned.  Between run_async and run_wait the handle accepts only wait_stored. */
+int mcmcpp_hip_run_async(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step);
+int mcmcpp_hip_wait_stored(mcmcpp_hip_sampler* h, int64_t count);
+int mcmcpp_hip_run_wait(mcmcpp_hip_sampler* h);
+
+/* Pinned (page-locked, device-visible) host memory for Chain blocks (stands in for the allocation of
+ * Chain/ChainBlock.h:115-131).  When chain_out of mcmcpp_hip_run lies in such memory the step launches forward stored
+ * steps straight into it: no staging ring on the host, no host copy.  NULL when the allocation fails. */
+void* mcmcpp_hip_host_alloc(uint64_t bytes);
+void mcmcpp_hip_host_free(void* p);
+
 /* Current walker state (what Walker::getCurrState / getCurrAuxData / getAcceptedProposals expose,
  * Walker/Walker.h:111-122).  n_accept[w] counts accepted proposals since set_state or reset_counters;
  * the reference additionally counts the initial placement (Walker.h:76,168) -- the facade adds it.
@@ -167,9 +201,17 @@ int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t c
  * ensemble step for ensembles small enough to be stepped by the full-step kernel, two (red, black) otherwise. */
 int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* step_launches);
 
+/* Host-side cost of the last mcmcpp_hip_run: the time the calling thread spent enqueueing the step launches (and, for a
+ * split ensemble, the exchanges), the wall time of the whole call, and -- split ensembles only -- the GPU time of one
+ * ensemble step's exchange, averaged over a sample of steps bracketed by HIP events (0 when none was sampled).
+ * Any pointer may be NULL. */
+int mcmcpp_hip_last_run_host_timing(mcmcpp_hip_sampler* h, double* enqueue_ms, double* wall_ms, double* exchange_us_per_step);
+
 /* ---- multi-GPU single ensemble (one handle per GPU) -------------------------------- */
 
-/* Enqueue ONE half-step (color 0 = red, 1 = black) for this handle's shard on its stream and return
+/* (A handle with a communicator needs none of these: mcmcpp_hip_run drives the split ensemble itself.  They remain for
+ * callers that bring their own exchange.)
+ * Enqueue ONE half-step (color 0 = red, 1 = black) for this handle's shard on its stream and return
  * without waiting.  The caller then exchanges the updated rows (device_positions + offset, see
  * mcmcpp_hip_shard_span) with the other handles -- e.g. an in-place RCCL all-gather on the same
  * stream -- before enqueueing the next half-step.  save_slot >= 0 also writes the shard's rows of

@@ -17,7 +17,9 @@ OK = 0
 EXPORTS = [
     "mcmcpp_hip_abi_version", "mcmcpp_hip_register_calculator", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
     "mcmcpp_hip_set_state", "mcmcpp_hip_seek", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
-    "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing",
+    "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing", "mcmcpp_hip_last_run_host_timing",
+    "mcmcpp_hip_comm_unique_id", "mcmcpp_hip_run_async", "mcmcpp_hip_wait_stored", "mcmcpp_hip_run_wait",
+    "mcmcpp_hip_host_alloc", "mcmcpp_hip_host_free",
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
     "mcmcpp_hip_moments_create", "mcmcpp_hip_moments_destroy", "mcmcpp_hip_moments_reset", "mcmcpp_hip_moments_add_steps",
@@ -33,9 +35,11 @@ class Config(C.Structure):
                 ("shard_begin", C.c_int32), ("shard_count", C.c_int32), ("graph_steps", C.c_int32),
                 ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32),
                 ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p), ("flags", C.c_uint32),
-                ("mover", C.c_uint32)]
+                ("mover", C.c_uint32), ("comm_world", C.c_int32), ("comm_rank", C.c_int32), ("comm_id", C.c_void_p),
+                ("comm", C.c_void_p)]
 
 FLAG_CALLER_STREAM = 1
+COMM_ID_BYTES = 128
 
 
 def library_path():
@@ -79,6 +83,16 @@ def lib():
         L.mcmcpp_hip_get_counters.argtypes = [vp, u64p, u64p, u64p, u64p]
         L.mcmcpp_hip_calc_logp.argtypes = [vp, vp, i64, vp]
         L.mcmcpp_hip_last_run_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+        dp = C.POINTER(C.c_double)
+        L.mcmcpp_hip_last_run_host_timing.argtypes = [vp, dp, dp, dp]
+        L.mcmcpp_hip_comm_unique_id.argtypes = [vp]
+        L.mcmcpp_hip_run_async.argtypes = [vp, i64, i32, vp, vp]
+        L.mcmcpp_hip_wait_stored.argtypes = [vp, i64]
+        L.mcmcpp_hip_run_wait.argtypes = [vp]
+        L.mcmcpp_hip_host_alloc.argtypes = [C.c_uint64]
+        L.mcmcpp_hip_host_alloc.restype = vp
+        L.mcmcpp_hip_host_free.argtypes = [vp]
+        L.mcmcpp_hip_host_free.restype = None
         L.mcmcpp_hip_half_step_async.argtypes = [vp, i32, i64]
         L.mcmcpp_hip_bind_device_chain.argtypes = [vp, vp, i64]
         L.mcmcpp_hip_device_positions.argtypes = [vp]
@@ -104,6 +118,39 @@ def lib():
     return _lib
 
 
+def comm_unique_id():
+    """The rendezvous token of a new RCCL communicator (make it on one rank, hand it to all)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().mcmcpp_hip_comm_unique_id(buf)
+    if rc != OK:
+        raise HipError(rc, lib().mcmcpp_hip_last_error(None).decode())
+    return buf.raw
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A numpy array in pinned host memory (mcmcpp_hip_host_alloc), e.g. a chain block the launches can write into."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    p = lib().mcmcpp_hip_host_alloc(n * dt.itemsize)
+    if not p:
+        raise MemoryError("mcmcpp_hip_host_alloc(%d) failed" % (n * dt.itemsize))
+    buf = (C.c_char * (n * dt.itemsize)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dt).reshape(shape)
+
+    class _Owner:
+        def __init__(self, p):
+            self.p = p
+
+        def __del__(self):
+            lib().mcmcpp_hip_host_free(self.p)
+
+    _PINNED_OWNERS[id(buf)] = (buf, _Owner(p))
+    return arr
+
+
+_PINNED_OWNERS = {}
+
+
 def np_dtype(dtype):
     return np.float64 if dtype == F64 else np.float32
 
@@ -122,14 +169,19 @@ class HipSampler:
     """Thin owner of one mcmcpp_hip_sampler handle (one GPU)."""
 
     def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, device=-1, shard_begin=0,
-                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1), mover=0):
+                 shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1), mover=0,
+                 comm_world=0, comm_rank=0, comm_id=None, comm=None):
+        """comm_world >= 1: this handle is rank comm_rank of a split ensemble (comm_id: the 128 bytes of comm_unique_id(),
+        the same on all ranks; or comm: an existing ncclComm_t as an integer); run() then steps the split ensemble."""
         self.W, self.D, self.dtype = W, D, dtype
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
+        self._comm_id = None if comm_id is None else C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
         self.cfg = Config(C.sizeof(Config), dtype, W, D, calc_id, 0 if self.params is None else self.params.size,
                           _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
                           shard_count, graph_steps, alpha[0], alpha[1], device_positions,
-                          0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, mover)
+                          0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, mover,
+                          comm_world, comm_rank, None if self._comm_id is None else C.cast(self._comm_id, C.c_void_p), comm)
         self.h = C.c_void_p()
         rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
         if rc != OK:
@@ -165,6 +217,20 @@ class HipSampler:
         self._check(lib().mcmcpp_hip_run(self.h, n_saved, interval, _ptr(chain), _ptr(acc)))
         return chain, acc
 
+    def run_async(self, n_saved, interval=1, out=None, want_accepted=False):
+        """Start the run on the handle's worker thread; returns (chain, acc) arrays that fill up as it proceeds."""
+        chain = out if out is not None else np.empty((n_saved, self.W, self.D), dtype=self.np_t)
+        acc = np.zeros(n_saved * interval, dtype=np.uint32) if want_accepted else None
+        self._async_keep = (chain, acc)
+        self._check(lib().mcmcpp_hip_run_async(self.h, n_saved, interval, _ptr(chain), _ptr(acc)))
+        return chain, acc
+
+    def wait_stored(self, count):
+        self._check(lib().mcmcpp_hip_wait_stored(self.h, count))
+
+    def run_wait(self):
+        self._check(lib().mcmcpp_hip_run_wait(self.h))
+
     def get_state(self):
         pos = np.empty((self.W, self.D), dtype=self.np_t)
         logp = np.empty(self.W, dtype=self.np_t)
@@ -190,6 +256,12 @@ class HipSampler:
         ms, n = C.c_double(0), C.c_int64(0)
         self._check(lib().mcmcpp_hip_last_run_timing(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def last_run_host_timing(self):
+        """(ms the host spent enqueueing, wall ms of the call, GPU us of one step's exchange -- split ensembles only)"""
+        v = [C.c_double(0) for _ in range(3)]
+        self._check(lib().mcmcpp_hip_last_run_host_timing(self.h, *[C.byref(x) for x in v]))
+        return v[0].value, v[1].value, v[2].value
 
     def half_step_async(self, color, save_slot=-1):
         self._check(lib().mcmcpp_hip_half_step_async(self.h, color, save_slot))

@@ -63,19 +63,27 @@ __host__ __device__ inline uint32_t full_step_bits(uint32_t half_bits, int pos_p
 // and second half of those walkers, 2 and 3 the black ones
 template <class T>
 __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, const RunInfo* run_ptr,
-                                                    bool block_barrier, DrawRec<T>* dn_red, int n, int wpb, int which, int lane)
+                                                    bool block_barrier, DrawRec<T>* dn_red, int n, int sh_begin, int sh_count, int wpb, int which, int lane)
 {
     const int black = kFullDrawWaves == 4 ? which >> 1 : which, half = kFullDrawWaves == 4 ? (which & 1) : 0;
     const int h0 = kFullDrawWaves == 4 ? (wpb + 1) / 2 : wpb;  // walkers of the first half
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
     // (the first of them also forwards this launch's slice of the last stored step: trickle_stored_step)
-    draw_wave_body<T, 1>(a, tab, ctl_ptr, block_barrier, dst, dst, 1, 0, n, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0,
+    draw_wave_body<T, 1>(a, tab, ctl_ptr, block_barrier, dst, dst, 1, sh_begin, sh_count, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0,
                          which == 0 ? run_ptr : nullptr);
 }
 
+// Both full-step kernels update walkers [sh_begin, sh_begin + sh_count) of EACH colour (the whole halves, or the slice
+// of one rank of a split ensemble: a black walker's group repeats the update of its red partner wherever that one
+// lives, so the ranks exchange rows once per ensemble step instead of once per half-step).  The bounds travel in the
+// 16 preloaded dwords; what they displaced is derived: the accepted counters lie right behind the two log-posterior
+// buffers ([2][W] elements, then [W] counters: one allocation), and the run record kRunBehindCtlBytes behind the
+// first control record.
+constexpr int kRunBehindCtlBytes = 256;
+
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
-stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const RunInfo* hot_run, uint32_t* hot_n_accept, int hot_n,
+stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const RunInfo* hot_run, int hot_sh_begin, int hot_sh_count, int hot_n,
                          uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     const HalfStepArgs<T>& a = rest;
@@ -96,7 +104,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     T* const hot_logp_b = hot_logp_a + 2 * (size_t)h_n;  // (the two log-posterior buffers are one allocation: [2][W])
     const T* const lin = h_flip ? hot_logp_b : hot_logp_a;
     T* const lout = h_flip ? hot_logp_a : hot_logp_b;
-    uint32_t* const h_n_accept = hot_n_accept;
+    uint32_t* const h_n_accept = reinterpret_cast<uint32_t*>(hot_logp_a + 4 * (size_t)h_n);
+    const int sh_begin = hot_sh_begin, sh_count = hot_sh_count;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
@@ -113,18 +122,18 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     if (wib >= kWavesPerBlock)
     {
         full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, Calc::block_scratch_elems(h_dims) != 0,
-                               dn_red, h_n, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane);
+                               dn_red, h_n, sh_begin, sh_count, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + wib;
-    const int first = wave * WPP;
-    const bool wave_active = first < h_n;
+    const int first = wave * WPP;  // (relative to the shard)
+    const bool wave_active = first < sh_count;
     const int sub = lane & (LPW - 1);
     const int grp = lane / LPW;
     const int i0 = sub * EPL;
     const int li = first + grp;
-    const bool active = li < h_n;
-    const int ir = active ? li : 0;  // this group's red walker, and (n + ir) its black walker
+    const bool active = li < sh_count;
+    const int ir = sh_begin + (active ? li : 0);  // this group's red walker, and (n + ir) its black walker
 
     GroupCtx<T, EPL, LPW> ctx;
     ctx.sub = sub;
@@ -204,8 +213,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
             const int c = t >= 3 * WPP ? 1 : 0;
             const int tt = t - 3 * WPP * c;
             const int slot = tt / 3, k = tt - 3 * slot;
-            if (first + slot >= h_n) continue;
-            const int i = first + slot;
+            if (first + slot >= sh_count) continue;
+            const int i = sh_begin + first + slot;
             Affine128 j_a, j_b;
             if (direct)
                 j_a = a.task_jump[3 * i + k];
@@ -322,7 +331,7 @@ __device__ __forceinline__ void store_row_piece(double* p, double x0, double x1)
 
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
-stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, const RunInfo* hot_run, int hot_n,
+stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, int hot_sh_begin, int hot_sh_count, int hot_n,
                               uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
@@ -353,17 +362,20 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     T* const lout = h_flip ? hot_logp_a : hot_logp_b;
     // (log-posteriors [2][W] and accepted counters [W] are one allocation: the counters' address is derived)
     uint32_t* const h_n_accept = reinterpret_cast<uint32_t*>(hot_logp_a + 4 * (size_t)h_n);
+    const int sh_begin = hot_sh_begin, sh_count = hot_sh_count;
+    // (the run record lies kRunBehindCtlBytes behind the first of the two control records; this launch reads record h_flip)
+    const RunInfo* const hot_run = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(hot_ctl_in - (h_flip ? 1 : 0)) + kRunBehindCtlBytes);
 
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
-        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, false, dn_red, h_n, kWavesPerBlock * NW,
-                               (int)(threadIdx.x >> 6) - kWavesPerBlock, lane);
+        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, false, dn_red, h_n, sh_begin, sh_count,
+                               kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    const int first = wave * NW;
-    if (first >= h_n) return;  // (no workgroup barrier in this kernel)
+    const int first = wave * NW;  // (relative to the shard)
+    if (first >= sh_count) return;  // (no workgroup barrier in this kernel)
     const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
     typedef double2 V2;
     const bool col_ok = i0 < h_dims;  // (even D only: rows are whole 16-byte pieces)
@@ -388,8 +400,8 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     for (int q = 0; q < 2; ++q)
     {
         const int li = first + 4 * q + grp;
-        active[q] = li < h_n;
-        ir[q] = active[q] ? li : 0;
+        active[q] = li < sh_count;
+        ir[q] = sh_begin + (active[q] ? li : 0);
         rec_r[q] = dr_red[ir[q]];
         rec_b[q] = dr_blk[ir[q]];
         load_row(pin, ir[q], own_r[q]);

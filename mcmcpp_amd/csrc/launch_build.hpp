@@ -41,7 +41,7 @@ void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
     const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr), a.pos_parity);
     hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
-                       st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.n_accept, a.n, bits, a.ctl_in, a);
+                       st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>
@@ -49,10 +49,10 @@ void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
     const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity);
-    // (logp_alt == logp + W and n_accept == logp + 2 W: the kernel derives them and takes the padded matrix and the
-    //  run record's address as preloaded arguments instead)
+    // (logp_alt == logp + W, n_accept == logp + 2 W and the run record kRunBehindCtlBytes behind the control records: the
+    //  kernel derives them and takes the padded matrix and the shard bounds as preloaded arguments instead)
     hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
-                       a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.run, a.n, bits, a.ctl_in, a);
+                       a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>

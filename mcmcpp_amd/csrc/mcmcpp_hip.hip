@@ -26,9 +26,17 @@
 #include "../../include/mcmcpp_hip.h"
 #define MCMCPP_DEFINE_REDUCE_KERNEL
 #include "launch_table.hpp"
+#include "rccl_dyn.hpp"
 #include "sampler_base.hpp"
 
 using namespace mcmcpp;
+
+#define NCCL_TRY(expr)                                                                                          \
+    do                                                                                                          \
+    {                                                                                                           \
+        ncclResult_t r_ = (expr);                                                                               \
+        if (r_ != ncclSuccess) return fail(MCMCPP_HIP_E_COMM, "%s failed: %s", #expr, rccl->GetErrorString(r_)); \
+    } while (0)
 
 namespace
 {
@@ -65,6 +73,50 @@ long env_long(const char* name, long fallback)
     const char* v = std::getenv(name);
     return (v && *v) ? std::strtol(v, nullptr, 10) : fallback;
 }
+
+// The library's tuning and diagnostic knobs (environment variables, DESIGN.md section 9 lists them).  Read ONCE, when a
+// handle is created; nothing on the launch path touches the environment.  Negative "unset" values mean "library default".
+struct Knobs
+{
+    long passes;                  // MCMCPP_HIP_PASSES                   walkers-per-wavefront rounds of the half-step kernels (0: chosen from the size)
+    long waves_per_simd;          // MCMCPP_HIP_WAVES_PER_SIMD           wavefronts per SIMD to reach before a wavefront takes more walkers (2)
+    long matrix_core_min_walkers; // MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS  smallest shard stepped by the matrix-core kernels (0; -1: never)
+    long matrix_core_4pass;       // MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS from this many walkers per half on: 16 walkers per wavefront (32768)
+    long full_step;               // MCMCPP_HIP_FULL_STEP                1: one launch per ensemble step for small ensembles (1)
+    long full_step_max_walkers;   // MCMCPP_HIP_FULL_STEP_MAX_WALKERS    largest ensemble stepped that way (32768)
+    long task_table_mb;           // MCMCPP_HIP_TASK_TABLE_MB            size limit of the one-entry-per-draw jump table (16)
+    long chain_subchunk_mb;       // MCMCPP_HIP_CHAIN_SUBCHUNK_MB        device chain staging per sub-chunk / ring budget (32)
+    long graph_steps;             // MCMCPP_HIP_GRAPH_STEPS              ensemble steps per hipGraph replay (-1 here: 300 up to 32768 walkers, else 128)
+    long debug_timing;            // MCMCPP_HIP_DEBUG_TIMING             1: run() prints its host-side phases to stderr
+    long trickle;                 // MCMCPP_HIP_TRICKLE                  1: stored steps forwarded to pinned memory by the launches (1)
+    long no_draw_wave;            // MCMCPP_HIP_NO_DRAW_WAVE             1: no extra draw wavefronts (0)
+    long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
+    long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
+    long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
+    long comm_emulate_ranks;      // MCMCPP_HIP_COMM_EMULATE_RANKS       diagnostic, single-rank communicators only: step the ensemble as G slices,
+                                  //                                     one launch each, as G ranks would (tests the sliced kernels on one GPU) (1)
+    static Knobs from_environment()
+    {
+        Knobs k;
+        k.passes = env_long("MCMCPP_HIP_PASSES", 0);
+        k.waves_per_simd = env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
+        k.matrix_core_min_walkers = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
+        k.matrix_core_4pass = env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768);
+        k.full_step = env_long("MCMCPP_HIP_FULL_STEP", 1);
+        k.full_step_max_walkers = env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 32768);
+        k.task_table_mb = env_long("MCMCPP_HIP_TASK_TABLE_MB", 16);
+        k.chain_subchunk_mb = env_long("MCMCPP_HIP_CHAIN_SUBCHUNK_MB", 32);
+        k.graph_steps = env_long("MCMCPP_HIP_GRAPH_STEPS", -1);
+        k.debug_timing = env_long("MCMCPP_HIP_DEBUG_TIMING", 0);
+        k.trickle = env_long("MCMCPP_HIP_TRICKLE", 1);
+        k.no_draw_wave = env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0);
+        k.copy_stream = env_long("MCMCPP_HIP_COPY_STREAM", 0);
+        k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
+        k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
+        k.comm_emulate_ranks = env_long("MCMCPP_HIP_COMM_EMULATE_RANKS", 1);
+        return k;
+    }
+};
 
 struct RegisteredCalc
 {
@@ -156,6 +208,7 @@ public:
     int init(const mcmcpp_hip_config& c)
     {
         cfg = c;
+        knobs = Knobs::from_environment();
         W = c.num_walkers;
         D = c.num_params;
         n = W / 2;
@@ -178,6 +231,21 @@ public:
 
         shard_begin = c.shard_begin;
         shard_count = c.shard_count > 0 ? c.shard_count : n;
+        if (c.comm_world >= 1)
+        {
+            // a rank of a split ensemble owns the comm_rank-th of comm_world equal slices of each half
+            if (c.comm_rank < 0 || c.comm_rank >= c.comm_world) return fail(MCMCPP_HIP_E_ARG, "comm_rank %d outside 0..%d", c.comm_rank, c.comm_world - 1);
+            if (n % c.comm_world) return fail(MCMCPP_HIP_E_ARG, "W/2 = %d does not divide by comm_world = %d", n, c.comm_world);
+            const int per = n / c.comm_world;
+            if (c.shard_count == 0)
+            {
+                shard_begin = c.comm_rank * per;
+                shard_count = per;
+            }
+            else if (shard_begin != c.comm_rank * per || shard_count != per)
+                return fail(MCMCPP_HIP_E_ARG, "the shard of rank %d of %d must be [%d, +%d)", c.comm_rank, c.comm_world, c.comm_rank * per, per);
+            if (!c.comm && !c.comm_id) return fail(MCMCPP_HIP_E_ARG, "comm_world >= 1 needs comm_id or comm");
+        }
         if (shard_begin < 0 || shard_begin + shard_count > n) return fail(MCMCPP_HIP_E_ARG, "shard out of range");
 
         int ndev = 0;
@@ -195,18 +263,41 @@ public:
             return fail(MCMCPP_HIP_E_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device,
                         prop.gcnArchName);
         num_cus = prop.multiProcessorCount;
+        if (c.comm_world >= 1)
+        {
+            std::string why;
+            rccl = Rccl::get(&why);
+            if (!rccl) return fail(MCMCPP_HIP_E_COMM, "%s", why.c_str());
+            if (c.comm)
+            {
+                comm = static_cast<ncclComm_t>(c.comm);
+                int cnt = -1, rk = -1;
+                NCCL_TRY(rccl->CommCount(comm, &cnt));
+                NCCL_TRY(rccl->CommUserRank(comm, &rk));
+                if (cnt != c.comm_world || rk != c.comm_rank)
+                    return fail(MCMCPP_HIP_E_ARG, "the communicator is rank %d of %d, the config says %d of %d", rk, cnt, c.comm_rank, c.comm_world);
+            }
+            else
+            {
+                ncclUniqueId id;
+                static_assert(sizeof(id) == MCMCPP_HIP_COMM_ID_BYTES, "mcmcpp_hip.h states the size of an RCCL id");
+                std::memcpy(&id, c.comm_id, sizeof id);
+                NCCL_TRY(rccl->CommInitRank(&comm, c.comm_world, id, c.comm_rank));
+                own_comm = true;
+            }
+        }
 
         // Walkers per wavefront: fill the chip first (about two wavefronts per SIMD), then up to 8 per wavefront (still
         // served by the draw wavefront) and 16 for the largest ensembles.  Measured, 32 dims fp64 (tools/sweep_passes.txt):
         // 65 536 walkers 5.2 / 5.8 / 4.4e9 walker-steps/s with 4 / 8 / 16 walkers per wavefront, 262 144: 7.4e9 with 8,
         // 1 M: 6.7 / 8.0 / 7.8 / 7.4e9 with 8 / 16 / 32 / 64.
         const int wpp = 64 / lpw;
-        long forced = env_long("MCMCPP_HIP_PASSES", 0);
+        long forced = knobs.passes;
         if (forced > 0)
             passes = (int)forced;
         else
         {
-            const long target_waves = (long)num_cus * 4 * env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
+            const long target_waves = (long)num_cus * 4 * knobs.waves_per_simd;
             const int per_wave_cap = shard_count > 196608 ? 16 : 8;
             passes = 1;
             while (passes * 2 <= lpw && wpp * passes * 2 <= per_wave_cap && (long)shard_count / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
@@ -215,19 +306,22 @@ public:
         if (passes > lpw) passes = lpw;
         // Matrix-core variants of the half-step kernel (dense calculators, fp64, even D in 18..32): the wavefront's
         // walkers are rows of one MFMA tile -- 8 walkers (2 passes) until the chip is full, 16 (4 passes) beyond.
-        const long mc_min = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
+        const long mc_min = knobs.matrix_core_min_walkers;
         if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
         {
-            const int big = shard_count >= env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768) ? 1 : 0;
+            const int big = shard_count >= knobs.matrix_core_4pass ? 1 : 0;
             half_fn = table->half_step_mc[big][lpw_log][epl_shift];
             passes = big ? 4 : 2;
         }
 
         // One launch per ensemble step (full_step_kernel.hpp) while the ensemble is small enough that a half-step
         // launch is bounded by its launch boundary and latencies rather than by HBM; needs the whole ensemble here.
+        // A rank of a split ensemble takes the same kernels for its slice (they repeat red updates owned by other ranks,
+        // so the ranks exchange rows once per ensemble step), by the size of what it updates.
         full_fn = nullptr;
-        if (shard_count == n && shard_begin == 0 && env_long("MCMCPP_HIP_FULL_STEP", 1) != 0 &&
-            W <= env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 32768))
+        const bool whole = shard_count == n && shard_begin == 0;
+        if ((whole ? knobs.full_step != 0 : (c.comm_world >= 1 && knobs.comm_full_step != 0 && knobs.full_step != 0)) &&
+            2 * (long)shard_count <= knobs.full_step_max_walkers)
         {
             full_fn = table->full_step[lpw_log][epl_shift];
             full_wpb = kWavesPerBlock * (64 / lpw);
@@ -287,13 +381,20 @@ public:
         d_nacc = reinterpret_cast<uint32_t*>(d_logp + 2 * (size_t)W);
         if (full_fn)
             if (int rc = carve(&d_pos_alt, sizeof(T) * (size_t)W * D)) return rc;
-        if (int rc = carve(&d_ctl, sizeof(StepCtl) * 2)) return rc;
-        if (int rc = carve(&d_run, sizeof(RunInfo))) return rc;
+        {
+            // the two control records and, kRunBehindCtlBytes behind the first, the run record: one piece (a kernel short
+            // of preloaded arguments derives the run record's address)
+            static_assert(2 * sizeof(StepCtl) <= (size_t)kRunBehindCtlBytes, "the run record follows the control records");
+            char* piece = nullptr;
+            if (int rc = carve(&piece, (size_t)kRunBehindCtlBytes + sizeof(RunInfo))) return rc;
+            d_ctl = reinterpret_cast<StepCtl*>(piece);
+            d_run = reinterpret_cast<RunInfo*>(piece + kRunBehindCtlBytes);
+        }
         if (int rc = carve(&d_diag, sizeof(Diag))) return rc;
         // the draw records (two buffers: see HalfStepArgs::draws) and, right behind them, the jump tables: one piece
         // whose layout follows from n alone (JumpTables), so that kernels reach the tables from the record pointer
         static_assert(sizeof(DrawRec<T>) == 32, "the table offsets assume 32-byte records");
-        have_task_table = (size_t)3 * n * sizeof(Affine128) <= ((size_t)env_long("MCMCPP_HIP_TASK_TABLE_MB", 16) << 20);
+        have_task_table = (size_t)3 * n * sizeof(Affine128) <= ((size_t)knobs.task_table_mb << 20);
         {
             char* piece = nullptr;
             if (int rc = carve(&piece, tables_total_bytes(n, have_task_table))) return rc;
@@ -361,12 +462,15 @@ public:
         }
 
         graph_steps = c.graph_steps == 0 ? (int)default_graph_steps() : c.graph_steps;
+        // HIP cannot capture on the legacy default stream (hipErrorStreamCaptureUnsupported): a caller that hands over
+        // NULL / hipStreamLegacy gets plain launches instead of graph replays
+        if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
         if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;
         if (int rc = carve(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves)) return rc;
         HIP_TRY(hipMemset(d_partials, 0, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
-        chain_subchunk_bytes = (size_t)env_long("MCMCPP_HIP_CHAIN_SUBCHUNK_MB", 32) << 20;
+        chain_subchunk_bytes = (size_t)knobs.chain_subchunk_mb << 20;
         return MCMCPP_HIP_OK;
     }
 
@@ -374,7 +478,7 @@ public:
     // sequence: ensembles small enough for one launch per step (5.6 us each) take 300 per replay -- with the bench's
     // slicing interval of 100 that is three stored steps per replay, as many as the forwarding ring allows; measured 1.5 %
     // over 128 -- larger ones, whose launches are long and whose per-step counters grow with the walker count, 128.
-    long default_graph_steps() const { return env_long("MCMCPP_HIP_GRAPH_STEPS", W <= 32768 ? 300 : 128); }
+    long default_graph_steps() const { return (knobs.graph_steps >= 0 ? knobs.graph_steps : (W <= 32768 ? 300 : 128)); }
 
     // Everything a step launch touches lives in ONE device allocation, carved here (one allocation, one free; tried as
     // a way to make the cold first accesses of a launch cheaper through fewer address translations: no measurable
@@ -415,6 +519,34 @@ public:
     // Everything is ordered by events; nothing is allocated on the way.
     int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) override
     {
+        run_touched_device = false;
+        const int rc = comm ? run_split(n_saved, interval, chain_out, accepted_per_step) : run_whole(n_saved, interval, chain_out, accepted_per_step);
+        if (rc != MCMCPP_HIP_OK && run_touched_device) abandon_state();
+        return rc;
+    }
+
+    // A failure after the first launch of a run leaves walkers, control records and draw records ahead of the host's
+    // counters (and possibly the live ensemble in the second buffer, or the stream in capture mode): nothing on the
+    // device can be trusted any more.  The handle then insists on a new set_state, as the DE sampler does.
+    void abandon_state()
+    {
+        const std::string keep = error;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+        {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+        }
+        (void)hipStreamSynchronize(stream);
+        (void)hipGetLastError();
+        have_state = false;
+        records_valid = false;
+        error = keep + " (the walker state on the device is no longer consistent: call set_state again)";
+    }
+
+    int run_whole(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+    {
         if (!have_state) return fail(MCMCPP_HIP_E_STATE, "run: set_state has not been called");
         if (n_saved < 0 || interval < 1) return fail(MCMCPP_HIP_E_ARG, "run: n_saved >= 0 and interval >= 1 required");
         if (shard_count != n) return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: a sharded handle is driven with half_step_async");
@@ -424,7 +556,7 @@ public:
         last_ms = 0.0;
         last_launches = 0;
         if (total == 0) return MCMCPP_HIP_OK;
-        const bool dbg = env_long("MCMCPP_HIP_DEBUG_TIMING", 0) != 0;
+        const bool dbg = knobs.debug_timing != 0;
         const auto tp0 = std::chrono::steady_clock::now();
 
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
@@ -438,7 +570,10 @@ public:
         }
         // Full-step kernels forward stored steps to pinned host memory themselves (trickle_stored_step): a ring of
         // `ring` slots on the device with a twin in pinned host memory, no copy engine, no gap in the launch sequence.
-        const bool trickle = full_fn && chain_out && step_bytes % 16 == 0 && env_long("MCMCPP_HIP_TRICKLE", 1) != 0;
+        const bool trickle = full_fn && chain_out && step_bytes % 16 == 0 && knobs.trickle != 0;
+        // chain_out in pinned host memory (mcmcpp_hip_host_alloc: the facade's Chain blocks): the launches forward stored
+        // steps straight into their final place -- no pinned twin of the device ring, no host copy
+        void* direct_stage = (trickle && knobs.pinned_direct != 0) ? device_view_of_pinned(chain_out, step_bytes * (size_t)n_saved) : nullptr;
         int64_t ring = 0, chunk_steps = 0;
         if (trickle)
         {
@@ -446,14 +581,15 @@ public:
             while (ring < 64 && (size_t)(2 * ring) * step_bytes <= 2 * chain_subchunk_bytes) ring *= 2;
             // the host enqueues one chunk ahead of the one it waits for: stored steps of two chunks are in flight
             int64_t per_chunk = (graph_steps > 0 ? graph_steps : 64) / (int64_t)interval;
-            if (per_chunk > (ring - 2) / 2) per_chunk = (ring - 2) / 2;
+            if (!direct_stage && per_chunk > (ring - 2) / 2) per_chunk = (ring - 2) / 2;
             if (per_chunk < 1) per_chunk = 1;
             chunk_steps = per_chunk * interval;
         }
         int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved : 0,
-                                    trickle ? step_bytes * (size_t)ring : 0);
+                                    trickle ? step_bytes * (size_t)ring : 0, direct_stage == nullptr);
         if (rc) return rc;
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
+        run_touched_device = true;  // from here on an error leaves the device ahead of the host's bookkeeping
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
         records_valid = false;  // (until this call has finished: an error on the way leaves them unknown)
@@ -474,7 +610,7 @@ public:
         double launch_ms = 0.0;  // GPU time of the step launches alone (downloads excluded)
         if (trickle)
         {
-            rc = run_trickle(n_saved, interval, (char*)chain_out, accepted_per_step != nullptr, step_bytes, ring, chunk_steps, &launch_ms);
+            rc = run_trickle(n_saved, interval, (char*)chain_out, accepted_per_step != nullptr, step_bytes, ring, chunk_steps, &launch_ms, (char*)direct_stage);
             sub_saved = n_saved + 1;  // (the sub-chunk loop below has nothing to do)
         }
         const int64_t n_sub = trickle ? 0 : (n_saved + sub_saved - 1) / sub_saved;
@@ -528,6 +664,7 @@ public:
                 {
                     HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
                     std::memcpy((char*)chain_out + step_bytes * (size_t)pending_first, h_stage[pending_buf], step_bytes * (size_t)pending_count);
+                    publish_stored(pending_first + pending_count);
                 }
                 pending_first = first;
                 pending_count = now;
@@ -541,6 +678,7 @@ public:
             {
                 HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
                 std::memcpy((char*)chain_out + step_bytes * (size_t)pending_first, h_stage[pending_buf], step_bytes * (size_t)pending_count);
+                publish_stored(pending_first + pending_count);
             }
             if (full_fn && (run_step & 1))
             {
@@ -569,6 +707,9 @@ public:
                 HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
         }
         const auto tp3 = std::chrono::steady_clock::now();
+        host_enqueue_ms = std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+        host_wall_ms = std::chrono::duration<double, std::milli>(tp3 - tp0).count();
+        exchange_us_per_step = 0.0;
         // (the device-side RunInfo still points to run-scoped buffers; half_step_async replaces it before it launches)
         if (dbg)
         {
@@ -582,6 +723,239 @@ public:
         return rc;
     }
 
+    // ---- one ensemble split over the ranks of an RCCL communicator (BASELINE config 5) -----------------
+    // Stands in for ParallelEnsembleSampler::runMCMC with threadCount workers (ParallelEnsembleSampler.h:285-291) and the
+    // controller's mid-step / end-step barriers (Threading/RedBlkCtrlerSpinLock.h:240-322).  Every rank holds the full
+    // replica of the positions and updates its slice; launches AND exchanges are enqueued on the launch stream by this
+    // host thread, nothing waits for the device until the end (stored steps excepted, a staging buffer at a time).
+    //   full-step kernels (slices of up to full_step_max_walkers / 2 walkers per colour): ONE exchange per ensemble
+    //     step.  A black walker's group repeats the red update of its partner wherever that one lives, so a rank needs
+    //     nothing from the others inside a step; afterwards the updated rows and log-posteriors of both colours are
+    //     all-gathered (in place: every rank's slice sits where the gather puts it) into the buffer the step wrote.  The
+    //     repeated updates read the red draw records of ALL walkers, which fill_draws_kernel makes per step (the
+    //     records of a rank's own walkers are also left behind by its draw wavefronts: same bits).
+    //   half-step kernels (larger slices): the reference's scheme, one exchange of the updated colour per half-step.
+    // The random stream is addressed by the global walker index, so the trajectory does not depend on the number of ranks.
+    int exchange_rows(T* pos_buf, T* logp_buf, int first_color, int colors)
+    {
+        NCCL_TRY(rccl->GroupStart());
+        for (int c = first_color; c < first_color + colors; ++c)
+        {
+            T* half = pos_buf + (size_t)c * n * D;
+            NCCL_TRY(rccl->AllGather(half + (size_t)shard_begin * D, half, (size_t)shard_count * D, RcclType<T>::value, comm, stream));
+            if (logp_buf)
+            {
+                T* lh = logp_buf + (size_t)c * n;
+                NCCL_TRY(rccl->AllGather(lh + shard_begin, lh, (size_t)shard_count, RcclType<T>::value, comm, stream));
+            }
+        }
+        NCCL_TRY(rccl->GroupEnd());
+        return MCMCPP_HIP_OK;
+    }
+
+    int run_split(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+    {
+        if (!have_state) return fail(MCMCPP_HIP_E_STATE, "run: set_state has not been called");
+        if (n_saved < 0 || interval < 1) return fail(MCMCPP_HIP_E_ARG, "run: n_saved >= 0 and interval >= 1 required");
+        if (half_steps & 1) return fail(MCMCPP_HIP_E_STATE, "run: an ensemble step is half done (half_step_async)");
+        HIP_TRY(hipSetDevice(device));
+        const int64_t total = n_saved * (int64_t)interval;
+        last_ms = 0.0;
+        last_launches = 0;
+        host_enqueue_ms = host_wall_ms = exchange_us_per_step = 0.0;
+        if (total == 0) return MCMCPP_HIP_OK;
+        const auto tp0 = std::chrono::steady_clock::now();
+        const size_t step_bytes = sizeof(T) * (size_t)W * D;
+
+        // stored steps: device -> pinned staging on the launch stream, handed to the caller a staging buffer at a time
+        int64_t stage_slots = 0;
+        if (chain_out)
+        {
+            stage_slots = (int64_t)(((size_t)256 << 20) / step_bytes);
+            if (stage_slots < 1) stage_slots = 1;
+            if (stage_slots > n_saved) stage_slots = n_saved;
+            if (step_bytes * (size_t)stage_slots > split_stage_capacity)
+            {
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (h_split_stage) hipHostFree(h_split_stage);
+                h_split_stage = nullptr;
+                split_stage_capacity = 0;
+                if (hipHostMalloc(&h_split_stage, step_bytes * (size_t)stage_slots, hipHostMallocDefault) != hipSuccess)
+                    return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of pinned staging", step_bytes * (size_t)stage_slots);
+                split_stage_capacity = step_bytes * (size_t)stage_slots;
+            }
+        }
+        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, 0, 0);
+        if (rc) return rc;
+        constexpr int kMaxSamples = 32;
+        if (ev_x.empty())
+        {
+            ev_x.assign(2 * kMaxSamples, nullptr);
+            for (hipEvent_t& e : ev_x) HIP_TRY(hipEventCreate(&e));
+        }
+        if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
+        run_touched_device = true;
+        rc = write_ctl(0);
+        if (rc) return rc;
+        records_valid = false;
+        run_info_idle = false;
+        {
+            RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256);
+            ri->chain = nullptr;  // (stored steps are copied from the replica after the exchange)
+            ri->accepted_per_step = accepted_per_step ? d_acc : nullptr;
+            ri->interval = interval;
+            ri->chain_slot_base = 0;
+            ri->stage = nullptr;
+            ri->slot_mask = -1;
+            ri->slice_bytes = 0;
+            ri->step_bytes = (int64_t)step_bytes;
+            HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+        }
+        if (full_fn)
+        {
+            hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, d_nacc, W, kRowMovedBit);
+            HIP_TRY(hipGetLastError());
+        }
+        enq_step = half_steps >> 1;
+        run_step = 0;
+        args_red = make_args(0);
+        args_blk = make_args(1);
+        // engine state in front of the red half-step of the coming ensemble step (what write_ctl put into the control record)
+        U128 red_base = apply(pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps), state0);
+        HalfStepArgs<T> fill_red = make_args(0);
+        fill_red.shard_begin = 0;
+        fill_red.shard_count = n;
+
+        // diagnostic (MCMCPP_HIP_COMM_EMULATE_RANKS = G, single-rank communicators): the slices of G ranks, one launch each
+        int emu = (int)knobs.comm_emulate_ranks;
+        if (emu < 1 || cfg.comm_world != 1 || shard_count % emu != 0) emu = 1;
+        const int emu_count = shard_count / emu;
+        const int emu_waves = (int)(full_fn ? full_grid_blocks_for(emu_count) : grid_blocks_for(emu_count)) * kWavesPerBlock;
+        if ((long)emu_waves * emu > partial_waves) emu = 1;
+        auto slice = [&](HalfStepArgs<T>& a, int r) {
+            a.shard_begin = shard_begin + r * (emu > 1 ? emu_count : 0);
+            a.shard_count = emu > 1 ? emu_count : shard_count;
+            a.partials = d_partials + (size_t)r * (emu > 1 ? emu_waves : 0);
+        };
+
+        const int64_t sample_stride = total > kMaxSamples ? total / kMaxSamples : 1;
+        int samples = 0;
+        int64_t staged = 0, handed = 0;  // stored steps copied to staging / handed to the caller
+        auto drain_stage = [&]() -> int {
+            HIP_TRY(hipStreamSynchronize(stream));
+            std::memcpy((char*)chain_out + step_bytes * (size_t)handed, h_split_stage, step_bytes * (size_t)(staged - handed));
+            handed = staged;
+            publish_stored(handed);
+            return MCMCPP_HIP_OK;
+        };
+        HIP_TRY(hipEventRecord(ev_t0[0], stream));
+        const auto tp1 = std::chrono::steady_clock::now();
+        for (int64_t s = 0; s < total; ++s)
+        {
+            const int parity = (int)(enq_step & 1), pos_parity = (int)(run_step & 1);
+            const bool sample = samples < kMaxSamples && s % sample_stride == 0;
+            T* cur_pos = d_pos;  // the replica that holds the ensemble after this step
+            if (full_fn)
+            {
+                fill_red.draw_parity = parity;
+                launch_fill_draws(fill_red, red_base, nullptr, stream);
+                for (int r = 0; r < emu; ++r)
+                {
+                    slice(args_red, r);
+                    enqueue_step(parity, pos_parity);
+                }
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
+                HIP_TRY(hipGetLastError());
+                cur_pos = pos_parity ? d_pos : d_pos_alt;
+                T* cur_logp = pos_parity ? d_logp : d_logp + W;
+                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
+                rc = exchange_rows(cur_pos, cur_logp, 0, 2);
+                if (rc) return rc;
+                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
+                red_base = apply(half_jump, apply(half_jump, red_base));
+            }
+            else
+            {
+                args_red.draw_parity = parity;
+                args_blk.draw_parity = parity;
+                for (int r = 0; r < emu; ++r)
+                {
+                    slice(args_red, r);
+                    half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
+                }
+                HIP_TRY(hipGetLastError());
+                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
+                rc = exchange_rows(d_pos, nullptr, 0, 1);
+                if (rc) return rc;
+                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
+                for (int r = 0; r < emu; ++r)
+                {
+                    slice(args_blk, r);
+                    half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
+                }
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
+                HIP_TRY(hipGetLastError());
+                rc = exchange_rows(d_pos, nullptr, 1, 1);
+                if (rc) return rc;
+            }
+            if (sample) ++samples;
+            enq_step += 1;
+            run_step += 1;
+            if (chain_out && (s + 1) % interval == 0)
+            {
+                HIP_TRY(hipMemcpyAsync((char*)h_split_stage + step_bytes * (size_t)(staged - handed), cur_pos, step_bytes, hipMemcpyDeviceToHost, stream));
+                ++staged;
+                if (staged - handed == stage_slots && s + 1 < total)
+                    if ((rc = drain_stage())) return rc;
+            }
+        }
+        const auto tp2 = std::chrono::steady_clock::now();
+        if (full_fn && (run_step & 1))
+        {
+            HIP_TRY(hipMemcpyAsync(d_pos, d_pos_alt, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_logp, d_logp + W, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(d_ctl, d_ctl + 1, sizeof(StepCtl), hipMemcpyDeviceToDevice, stream));
+        }
+        HIP_TRY(hipEventRecord(ev_t1[0], stream));
+        // every rank ends the run with the whole ensemble's log-posteriors and accepted counters (get_state is then the
+        // same on all ranks), and with the ensemble-wide accepted counts per step
+        NCCL_TRY(rccl->GroupStart());
+        for (int c = 0; c < 2; ++c)
+        {
+            if (!full_fn)
+                NCCL_TRY(rccl->AllGather(d_logp + (size_t)c * n + shard_begin, d_logp + (size_t)c * n, (size_t)shard_count, RcclType<T>::value, comm, stream));
+            NCCL_TRY(rccl->AllGather(d_nacc + (size_t)c * n + shard_begin, d_nacc + (size_t)c * n, (size_t)shard_count, ncclUint32, comm, stream));
+        }
+        if (accepted_per_step) NCCL_TRY(rccl->AllReduce(d_acc, d_acc, (size_t)total, ncclUint32, ncclSum, comm, stream));
+        NCCL_TRY(rccl->GroupEnd());
+        if (chain_out && (rc = drain_stage())) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev_t0[0], ev_t1[0]));
+            last_ms = ms;
+            double sum = 0.0;
+            for (int k = 0; k < samples; ++k)
+            {
+                HIP_TRY(hipEventElapsedTime(&ms, ev_x[2 * k], ev_x[2 * k + 1]));
+                sum += ms;
+            }
+            // (half-step scheme: the sampled exchange is the red one, the black one moves as much)
+            exchange_us_per_step = samples ? sum / samples * 1e3 * (full_fn ? 1.0 : 2.0) : 0.0;
+        }
+        last_launches = full_fn ? total : 2 * total;
+        half_steps += 2 * (uint64_t)total;
+        steps_since_reset += (uint64_t)total;
+        records_valid = full_fn == nullptr;  // (full-step scheme: the next run re-primes, the red records of other ranks' walkers are per step anyway)
+        records_step = half_steps >> 1;
+        records_partner2 = false;
+        if (accepted_per_step) HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
+        const auto tp3 = std::chrono::steady_clock::now();
+        host_enqueue_ms = std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+        host_wall_ms = std::chrono::duration<double, std::milli>(tp3 - tp0).count();
+        return MCMCPP_HIP_OK;
+    }
+
     // The chain path of the full-step kernels.  Stored step k is complete in the pinned ring when ensemble step
     // (k + 2) * interval - 1 has finished (every launch forwards 1/interval of the previous stored step), and its
     // ring slot is overwritten from step (k + ring + 1) * interval on: the host enqueues chunks of steps, stays one
@@ -589,17 +963,18 @@ public:
     // run into a slot it has not copied yet.  The run's last stored step has no launches behind it: it is copied
     // from the device ring at the end.
     int run_trickle(int64_t n_saved, int32_t interval, char* chain_out, bool want_accepted, size_t step_bytes, int64_t ring,
-                    int64_t chunk_steps, double* launch_ms)
+                    int64_t chunk_steps, double* launch_ms, char* direct_stage)
     {
         const int64_t total = n_saved * (int64_t)interval;
+        const bool direct = direct_stage != nullptr;  // the launches forward into chain_out itself (pinned memory)
         RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256);
         ri->chain = d_ring;
         ri->accepted_per_step = want_accepted ? d_acc : nullptr;
         ri->interval = interval;
         ri->chain_slot_base = 0;
-        ri->stage = h_ring;
+        ri->stage = direct ? (void*)direct_stage : h_ring;
         ri->slot_mask = ring - 1;
-        ri->slice_bytes = (int64_t)(((step_bytes + (size_t)interval - 1) / (size_t)interval + 15) / 16 * 16);
+        ri->slice_bytes = (int64_t)(((step_bytes + (size_t)interval - 1) / (size_t)interval + 15) / 16 * 16) | (direct ? 1 : 0);
         ri->step_bytes = (int64_t)step_bytes;
         HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
 
@@ -613,15 +988,21 @@ public:
             HIP_TRY(hipEventElapsedTime(&ms, ev_t0[e], ev_t1[e]));
             *launch_ms += ms;
             const int64_t complete = chunk_end[e] / interval - 1;  // stored steps fully forwarded by now
-            for (; copied < complete; ++copied)
+            if (direct)
             {
-                char* dst = chain_out + step_bytes * (size_t)copied;
-                const char* src = (char*)h_ring + step_bytes * (size_t)(copied & (ring - 1));
-                if (enq == total)
-                    parallel_memcpy(dst, src, step_bytes);  // nothing left to overlap with: be quick
-                else
-                    std::memcpy(dst, src, step_bytes);
+                if (complete > copied) copied = complete;  // (they are where they belong already)
             }
+            else
+                for (; copied < complete; ++copied)
+                {
+                    char* dst = chain_out + step_bytes * (size_t)copied;
+                    const char* src = (char*)h_ring + step_bytes * (size_t)(copied & (ring - 1));
+                    if (enq == total)
+                        parallel_memcpy(dst, src, step_bytes);  // nothing left to overlap with: be quick
+                    else
+                        std::memcpy(dst, src, step_bytes);
+                }
+            publish_stored(copied);
             ++oldest;
             return MCMCPP_HIP_OK;
         };
@@ -629,7 +1010,9 @@ public:
         {
             const int64_t now = (total - enq < chunk_steps) ? total - enq : chunk_steps;
             // at most two chunks in flight, and no launch may forward into a ring slot that is still to be copied out
-            while (next_chunk > oldest && (next_chunk - oldest >= 2 || enq + now > (copied + ring + 1) * (int64_t)interval))
+            // (forwarding into the final place needs no such care: a device slot is reused ring + 1 stored steps after it
+            //  was written, its forwarding is over one stored step after)
+            while (next_chunk > oldest && (next_chunk - oldest >= 2 || (!direct && enq + now > (copied + ring + 1) * (int64_t)interval)))
             {
                 const int rc = process_oldest();
                 if (rc) return rc;
@@ -647,7 +1030,8 @@ public:
         // launch, so that it runs while the host still copies out the steps before it.
         {
             const size_t off = step_bytes * (size_t)((n_saved - 1) & (ring - 1));
-            HIP_TRY(hipMemcpyAsync((char*)h_ring + off, (char*)d_ring + off, step_bytes, hipMemcpyDeviceToHost, stream));
+            char* dst = direct ? chain_out + step_bytes * (size_t)(n_saved - 1) : (char*)h_ring + off;
+            HIP_TRY(hipMemcpyAsync(dst, (char*)d_ring + off, step_bytes, hipMemcpyDeviceToHost, stream));
         }
         while (next_chunk > oldest)
         {
@@ -655,16 +1039,40 @@ public:
             if (rc) return rc;
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        for (; copied < n_saved; ++copied)  // (exactly one: every earlier one has been forwarded and copied above)
-        {
-            const size_t off = step_bytes * (size_t)(copied & (ring - 1));
-            parallel_memcpy(chain_out + step_bytes * (size_t)copied, (char*)h_ring + off, step_bytes);
-        }
+        if (direct)
+            copied = n_saved;
+        else
+            for (; copied < n_saved; ++copied)  // (exactly one: every earlier one has been forwarded and copied above)
+            {
+                const size_t off = step_bytes * (size_t)(copied & (ring - 1));
+                parallel_memcpy(chain_out + step_bytes * (size_t)copied, (char*)h_ring + off, step_bytes);
+            }
+        publish_stored(copied);
         return MCMCPP_HIP_OK;
+    }
+
+    // Device-visible address of [p, p + bytes) when that range is pinned host memory (hipHostMalloc / mcmcpp_hip_host_alloc),
+    // nullptr for pageable memory.
+    void* device_view_of_pinned(void* p, size_t bytes)
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, p) != hipSuccess || at.type != hipMemoryTypeHost || at.devicePointer == nullptr)
+        {
+            (void)hipGetLastError();  // (pageable memory is reported as an error)
+            return nullptr;
+        }
+        hipPointerAttribute_t last;
+        if (hipPointerGetAttributes(&last, (char*)p + bytes - 1) != hipSuccess || last.type != hipMemoryTypeHost)
+        {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        return at.devicePointer;
     }
 
     int get_state(void* pos, void* logp, uint32_t* n_accept) override
     {
+        if (!have_state) return fail(MCMCPP_HIP_E_STATE, "get_state: no walker state (set_state has not been called, or a run failed half way)");
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamSynchronize(stream));
         if (pos) HIP_TRY(hipMemcpy(pos, d_pos, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToHost));
@@ -840,14 +1248,16 @@ private:
         return MCMCPP_HIP_OK;
     }
 
-    unsigned grid_blocks() const
+    unsigned grid_blocks() const { return grid_blocks_for(shard_count); }
+    unsigned grid_blocks_for(int count) const
     {
         const long per_wave = (long)(64 / lpw) * passes;
-        const long waves = (shard_count + per_wave - 1) / per_wave;
+        const long waves = (count + per_wave - 1) / per_wave;
         return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     }
 
-    unsigned full_grid_blocks() const { return (unsigned)((n + full_wpb - 1) / full_wpb); }
+    unsigned full_grid_blocks() const { return full_grid_blocks_for(shard_count); }
+    unsigned full_grid_blocks_for(int count) const { return (unsigned)((count + full_wpb - 1) / full_wpb); }
 
     HalfStepArgs<T> make_args(int color, int parity) const
     {
@@ -904,7 +1314,7 @@ private:
         a.pos_parity = 0;
         a.calc_params_padded = d_params_padded;
         // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
-        a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
+        a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && knobs.no_draw_wave == 0) ? 1 : 0;
         return a;
     }
 
@@ -950,14 +1360,14 @@ private:
             a.ctl_out = d_ctl + (1 - pos_parity);
             a.partial_waves = partial_waves;
             // the next draws by four extra wavefronts (two per colour) when that is one round of 64 draws each
-            a.draw_wave = (3 * (kFullDrawWaves == 4 ? (full_wpb + 1) / 2 : full_wpb) <= 64 && env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0) == 0) ? 1 : 0;
-            full_fn(a, full_grid_blocks(), stream);
+            a.draw_wave = (3 * (kFullDrawWaves == 4 ? (full_wpb + 1) / 2 : full_wpb) <= 64 && knobs.no_draw_wave == 0) ? 1 : 0;
+            full_fn(a, full_grid_blocks_for(a.shard_count), stream);
             return;
         }
         args_red.draw_parity = parity;
         args_blk.draw_parity = parity;
-        half_fn(args_red, grid_blocks(), stream);
-        half_fn(args_blk, grid_blocks(), stream);
+        half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
+        half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
     }
 
     // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
@@ -1036,20 +1446,26 @@ private:
 
     // persistent per-run buffers, grown on demand: per-step accepted counters, the two halves of the device
     // chain and their pinned staging twins
-    int ensure_run_buffers(size_t acc_entries, size_t half_bytes, size_t ring_bytes)
+    int ensure_run_buffers(size_t acc_entries, size_t half_bytes, size_t ring_bytes, bool need_host_ring = true)
     {
         if (ring_bytes > ring_capacity)
         {
             HIP_TRY(hipStreamSynchronize(stream));
             if (d_ring) hipFree(d_ring);
-            if (h_ring) hipHostFree(h_ring);
             d_ring = nullptr;
-            h_ring = nullptr;
             ring_capacity = 0;
             if (hipMalloc(&d_ring, ring_bytes) != hipSuccess) return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of device chain", ring_bytes);
+            ring_capacity = ring_bytes;
+        }
+        if (need_host_ring && ring_bytes > host_ring_capacity)
+        {
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (h_ring) hipHostFree(h_ring);
+            h_ring = nullptr;
+            host_ring_capacity = 0;
             if (hipHostMalloc(&h_ring, ring_bytes, hipHostMallocDefault) != hipSuccess)
                 return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of pinned staging", ring_bytes);
-            ring_capacity = ring_bytes;
+            host_ring_capacity = ring_bytes;
         }
         if (acc_entries > acc_capacity)
         {
@@ -1064,7 +1480,7 @@ private:
         {
             for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ev_copied[k], hipEventDisableTiming));
             for (int k = 0; k < 2; ++k) HIP_TRY(hipEventCreateWithFlags(&ev_filled[k], hipEventDisableTiming));
-            if (env_long("MCMCPP_HIP_COPY_STREAM", 0) != 0) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+            if (knobs.copy_stream != 0) HIP_TRY(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
         }
         if (half_bytes > chain_half_capacity)
         {
@@ -1120,10 +1536,21 @@ private:
             hipStreamSynchronize(copy_stream);
             hipStreamDestroy(copy_stream);
         }
+        if (own_comm && comm && rccl) (void)rccl->CommDestroy(comm);
+        if (h_split_stage) hipHostFree(h_split_stage);
+        for (hipEvent_t e : ev_x)
+            if (e) hipEventDestroy(e);
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
     mcmcpp_hip_config cfg;
+    Knobs knobs;
+    const Rccl* rccl = nullptr;  // split ensembles only
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    void* h_split_stage = nullptr;  // split ensembles: pinned staging of stored steps
+    size_t split_stage_capacity = 0;
+    std::vector<hipEvent_t> ev_x;   // split ensembles: events around a sample of exchanges
     const LaunchTable<T>* table = nullptr;
     typename LaunchTable<T>::HalfStepFn half_fn = nullptr;
     typename LaunchTable<T>::HalfStepFn full_fn = nullptr;  // non-null: run() steps with one launch per ensemble step
@@ -1138,13 +1565,13 @@ private:
     void* arena = nullptr;  // one device allocation holding everything a step launch touches (see carve)
     size_t arena_bytes = 0, arena_used = 0;
     void *d_ring = nullptr, *h_ring = nullptr;  // full-step chain path: device ring of stored steps and its pinned host twin
-    size_t ring_capacity = 0;
+    size_t ring_capacity = 0, host_ring_capacity = 0;
     hipStream_t copy_stream = nullptr;  // experiment (MCMCPP_HIP_COPY_STREAM=1): chain downloads beside the launches
     T* d_chain[2] = {nullptr, nullptr};
     void* h_stage[2] = {nullptr, nullptr};
     uint32_t* d_acc = nullptr;
     hipStream_t stream = nullptr;
-    bool own_stream = false, own_pos = false, have_state = false, stream_valid = false;
+    bool own_stream = false, own_pos = false, have_state = false, stream_valid = false, run_touched_device = false;
     hipEvent_t ev_t0[4] = {nullptr, nullptr, nullptr, nullptr}, ev_t1[4] = {nullptr, nullptr, nullptr, nullptr};
     T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_params_padded = nullptr;
     uint32_t* d_nacc = nullptr;
@@ -1214,7 +1641,8 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
     }
     if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
     if (c->mover != MCMCPP_HIP_MOVER_STRETCH && c->mover != MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION) BAD("unknown mover %u", c->mover);
-    if (c->mover == MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION && (c->shard_count != 0 || c->device_positions))
+    if (c->comm_world < 0) BAD("comm_world must not be negative");
+    if (c->mover == MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION && (c->shard_count != 0 || c->device_positions || c->comm_world >= 1))
         BAD("the differential-evolution mover runs one whole ensemble per handle (no shards, no caller-owned position buffer)");
     if (c->gw_alpha_num < 0 || c->gw_alpha_den < 0 || ((c->gw_alpha_num == 0) != (c->gw_alpha_den == 0)))
         BAD("gw_alpha_num/gw_alpha_den must both be positive (or both 0 for the default 2/1)");
@@ -1319,6 +1747,69 @@ int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, voi
     NEED_H;
     return h->run(n_saved, interval, chain_out, accepted_per_step);
 }
+int mcmcpp_hip_run_async(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+{
+    NEED_H;
+    if (h->async_active) return h->fail(MCMCPP_HIP_E_STATE, "run_async: the previous asynchronous run has not been waited for (mcmcpp_hip_run_wait)");
+    {
+        std::lock_guard<std::mutex> lock(h->async_mutex);
+        h->async_stored = 0;
+        h->async_done = false;
+        h->async_rc = MCMCPP_HIP_OK;
+    }
+    h->async_active = true;
+    try
+    {
+        h->async_worker = std::thread([=]() {
+            const int rc = h->run(n_saved, interval, chain_out, accepted_per_step);
+            {
+                std::lock_guard<std::mutex> lock(h->async_mutex);
+                h->async_rc = rc;
+                h->async_done = true;
+                if (rc == MCMCPP_HIP_OK && chain_out) h->async_stored = n_saved;  // (whatever the sampler announced on the way)
+            }
+            h->async_cv.notify_all();
+        });
+    }
+    catch (...)
+    {
+        h->async_active = false;
+        h->async_done = true;
+        return h->fail(MCMCPP_HIP_E_NOMEM, "run_async: cannot start the worker thread");
+    }
+    return MCMCPP_HIP_OK;
+}
+int mcmcpp_hip_wait_stored(mcmcpp_hip_sampler* h, int64_t count)
+{
+    NEED_H;
+    if (!h->async_active) return h->fail(MCMCPP_HIP_E_STATE, "wait_stored: no asynchronous run in progress");
+    std::unique_lock<std::mutex> lock(h->async_mutex);
+    h->async_cv.wait(lock, [&]() { return h->async_stored >= count || h->async_done; });
+    if (h->async_stored >= count) return MCMCPP_HIP_OK;
+    return h->async_rc != MCMCPP_HIP_OK ? h->async_rc : MCMCPP_HIP_E_ARG;  // the run ended without storing that many steps
+}
+int mcmcpp_hip_run_wait(mcmcpp_hip_sampler* h)
+{
+    NEED_H;
+    if (!h->async_active) return h->fail(MCMCPP_HIP_E_STATE, "run_wait: no asynchronous run in progress");
+    if (h->async_worker.joinable()) h->async_worker.join();
+    h->async_active = false;
+    return h->async_rc;
+}
+void* mcmcpp_hip_host_alloc(uint64_t bytes)
+{
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 64, hipHostMallocDefault) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void mcmcpp_hip_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
 int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept)
 {
     NEED_H;
@@ -1349,6 +1840,38 @@ int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* s
 {
     NEED_H;
     return h->last_run_timing(gpu_ms, step_launches);
+}
+int mcmcpp_hip_last_run_host_timing(mcmcpp_hip_sampler* h, double* enqueue_ms, double* wall_ms, double* exchange_us_per_step)
+{
+    NEED_H;
+    if (enqueue_ms) *enqueue_ms = h->host_enqueue_ms;
+    if (wall_ms) *wall_ms = h->host_wall_ms;
+    if (exchange_us_per_step) *exchange_us_per_step = h->exchange_us_per_step;
+    return MCMCPP_HIP_OK;
+}
+int mcmcpp_hip_comm_unique_id(void* id_out)
+{
+    if (!id_out)
+    {
+        g_create_error = "comm_unique_id: id_out is NULL";
+        return MCMCPP_HIP_E_ARG;
+    }
+    std::string why;
+    const Rccl* r = Rccl::get(&why);
+    if (!r)
+    {
+        g_create_error = why;
+        return MCMCPP_HIP_E_COMM;
+    }
+    ncclUniqueId id;
+    const ncclResult_t rc = r->GetUniqueId(&id);
+    if (rc != ncclSuccess)
+    {
+        g_create_error = std::string("ncclGetUniqueId failed: ") + r->GetErrorString(rc);
+        return MCMCPP_HIP_E_COMM;
+    }
+    std::memcpy(id_out, &id, sizeof id);
+    return MCMCPP_HIP_OK;
 }
 int mcmcpp_hip_half_step_async(mcmcpp_hip_sampler* h, int32_t color, int64_t save_slot)
 {

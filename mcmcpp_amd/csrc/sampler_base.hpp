@@ -4,16 +4,42 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/mcmcpp_hip.h"
 
 struct mcmcpp_hip_sampler
 {
     std::string error;
-    virtual ~mcmcpp_hip_sampler() {}
+    // host-side cost of the last run (mcmcpp_hip_last_run_host_timing)
+    double host_enqueue_ms = 0.0, host_wall_ms = 0.0, exchange_us_per_step = 0.0;
+    // mcmcpp_hip_run_async: the run executes on a worker thread owned by the handle; stored steps are announced as they
+    // reach the caller's memory
+    std::thread async_worker;
+    std::mutex async_mutex;
+    std::condition_variable async_cv;
+    int64_t async_stored = 0;   // stored steps of the current run that are complete in chain_out
+    bool async_active = false;  // a worker has been started and not yet joined
+    bool async_done = true;     // the worker's run has returned
+    int async_rc = 0;
+    void publish_stored(int64_t count)
+    {
+        {
+            std::lock_guard<std::mutex> lock(async_mutex);
+            if (count > async_stored) async_stored = count;
+        }
+        async_cv.notify_all();
+    }
+    virtual ~mcmcpp_hip_sampler()
+    {
+        if (async_worker.joinable()) async_worker.join();
+    }
     virtual int set_state(const void* pos, const void* logp) = 0;
     virtual int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) = 0;
     virtual int get_state(void* pos, void* logp, uint32_t* n_accept) = 0;

@@ -60,7 +60,7 @@ struct RunInfo
     // most recent stored step to its twin in pinned host memory (trickle_stored_step); nullptr: no forwarding
     void* stage;
     int64_t slot_mask;           // stored step k lives in slot k & slot_mask (all ones: slots are not reused)
-    int64_t slice_bytes;         // bytes of a stored step forwarded per launch (a multiple of 16)
+    int64_t slice_bytes;         // bytes of a stored step forwarded per launch (a multiple of 16) | bit 0: stage slots are not reused
     int64_t step_bytes;          // W * D * sizeof(T) (a multiple of 16 when stage != nullptr)
 };
 
@@ -518,11 +518,14 @@ __device__ __forceinline__ void trickle_stored_step(const RunInfo& run, const St
     if (run.stage == nullptr || prev < 0) return;
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const size_t slot_off = (size_t)(prev & run.slot_mask) * (size_t)run.step_bytes;
-    const size_t begin = (size_t)ctl.save_phase * (size_t)run.slice_bytes;
-    size_t end = begin + (size_t)run.slice_bytes;
+    // bit 0 of slice_bytes: `stage` is the stored steps' FINAL place (a pinned Chain block: slot = stored step index),
+    // not a ring that mirrors the device's
+    const size_t slice = (size_t)(run.slice_bytes & ~(int64_t)15);
+    const size_t begin = (size_t)ctl.save_phase * slice;
+    size_t end = begin + slice;
     if (end > (size_t)run.step_bytes) end = (size_t)run.step_bytes;
     const char* src = static_cast<const char*>(run.chain) + slot_off;
-    char* dst = static_cast<char*>(run.stage) + slot_off;
+    char* dst = static_cast<char*>(run.stage) + ((run.slice_bytes & 1) ? (size_t)prev * (size_t)run.step_bytes : slot_off);
     for (size_t off = begin + ((size_t)blockIdx.x * 64 + (size_t)lane) * 16; off < end; off += (size_t)gridDim.x * 64 * 16)
         store_through16(dst + off, *reinterpret_cast<const v4u*>(src + off));
 }

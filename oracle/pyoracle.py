@@ -44,11 +44,13 @@ def build(force=False):
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(so)
             for f in ("stretch_oracle.c", "stretch_oracle_typed.inc", "stretch_oracle.h")):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    ref = os.path.join(_HERE, "_ref", "libmcmcpp_ref.so")
-    if os.path.exists("/root/reference/MCMCpp/EnsembleSampler.h") and (
-            force or not os.path.exists(ref)
-            or os.path.getmtime(os.path.join(_HERE, "ref_driver.cpp")) > os.path.getmtime(ref)):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    if os.path.exists("/root/reference/MCMCpp/EnsembleSampler.h"):
+        for name in ("libmcmcpp_ref.so", "libmcmcpp_ref_o3.so"):
+            ref = os.path.join(_HERE, "_ref", name)
+            if (force or not os.path.exists(ref)
+                    or os.path.getmtime(os.path.join(_HERE, "ref_driver.cpp")) > os.path.getmtime(ref)):
+                subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+                break
 
 
 _lib = None
@@ -224,8 +226,23 @@ def reference_available():
     return os.path.exists(os.path.join(_HERE, "_ref", "libmcmcpp_ref.so"))
 
 
-def ref_lib():
-    global _ref
+_ref_timed = None
+
+
+def ref_lib(timed_build=False):
+    """timed_build: the reference at its own optimisation level (oracle/Makefile: -O3, contraction on) -- for timing
+    only; parity work uses the contraction-off build."""
+    global _ref, _ref_timed
+    if timed_build:
+        if _ref_timed is None:
+            build()
+            path = os.path.join(_HERE, "_ref", "libmcmcpp_ref_o3.so")
+            R = C.CDLL(path)
+            R.ref_run.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            _ref_timed = R
+        return _ref_timed
     if _ref is None:
         build()
         R = C.CDLL(os.path.join(_HERE, "_ref", "libmcmcpp_ref.so"))
@@ -242,8 +259,13 @@ def ref_lib():
     return _ref
 
 
+def timed_reference_available():
+    build()
+    return os.path.exists(os.path.join(_HERE, "_ref", "libmcmcpp_ref_o3.so"))
+
+
 def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_call, slicing=1, want_chain=True,
-                  threads=0, dtype=F64, alpha_code=0):
+                  threads=0, dtype=F64, alpha_code=0, timed_build=False):
     """Run MCMC::EnsembleSampler (threads=0) or ParallelEnsembleSampler (threads>=1) of the reference.
     alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>; 2: Mover::DifferentialEvolution.
 
@@ -260,7 +282,7 @@ def reference_run(W, D, calc_id, params, seed, pos, logp, n_calls, steps_per_cal
     stored = C.c_int(0)
     secs = C.c_double(0)
     frac = C.c_double(0)
-    rc = ref_lib().ref_run(dtype, threads, alpha_code, W, D, calc_id, _ptr(prm), seed, _ptr(pos), _ptr(logp), n_calls,
+    rc = ref_lib(timed_build).ref_run(dtype, threads, alpha_code, W, D, calc_id, _ptr(prm), seed, _ptr(pos), _ptr(logp), n_calls,
                            steps_per_call, slicing, _ptr(chain), cap, _ptr(acc), _ptr(tot), C.byref(stored),
                            C.byref(secs), C.byref(frac))
     if rc < 0:

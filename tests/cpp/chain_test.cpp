@@ -39,6 +39,30 @@ static void fill(ChainD& c, long steps, int W, int D, long first = 0)
     }
 }
 
+// a block-memory provider that counts its calls
+struct ProviderCalls
+{
+    static long obtained, released;
+    static unsigned long long lastBytes;
+    static bool fail;
+    static void* obtain(unsigned long long bytes)
+    {
+        if (fail) return nullptr;
+        ++obtained;
+        lastBytes = bytes;
+        void* p = nullptr;
+        return posix_memalign(&p, 64, bytes) == 0 ? p : nullptr;
+    }
+    static void release(void* p)
+    {
+        ++released;
+        std::free(p);
+    }
+};
+long ProviderCalls::obtained = 0, ProviderCalls::released = 0;
+unsigned long long ProviderCalls::lastBytes = 0;
+bool ProviderCalls::fail = false;
+
 int main()
 {
     const int W = 6, D = 3;
@@ -136,6 +160,73 @@ int main()
         // sizes that overflow the reference's 32-bit indexing (ChainBlock.h:116-128): 131072 x 64 walkers
         MCMC::Chain::Chain<float> big(131072, 64, 3ULL * 131072 * 64 * sizeof(float));
         CHECK(big.getMaxStepCount() == 3 && big.getCellsPerStep() == 131072LL * 64);
+    }
+    {
+        // blocks from a caller-supplied memory provider (the samplers hand out pinned host memory,
+        // Device/SamplerCore.h): every block is obtained from it and returned to it, contents and iterators as before;
+        // a provider that fails falls back to the heap
+        ProviderCalls::obtained = ProviderCalls::released = 0;
+        {
+            ChainD c(W, D, 11 * stepBytes, 4 * stepBytes, MCMC::Chain::Detail::BlockMemory(&ProviderCalls::obtain, &ProviderCalls::release));
+            fill(c, 11, W, D);
+            CHECK(ProviderCalls::obtained == 3 && ProviderCalls::released == 0);
+            CHECK(ProviderCalls::lastBytes == 3 * stepBytes);  // the last block holds what is left of the budget
+            long s = 0;
+            for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != c.getStepIteratorEnd(); ++it, ++s)
+                CHECK((*it)[W * D - 1] == cell(s, W - 1, D - 1));
+            CHECK(s == 11);
+            std::int64_t room = 0;
+            CHECK(c.stepsContiguousFrom(&room) == nullptr && room == 0);
+        }
+        CHECK(ProviderCalls::released == 3);
+        ProviderCalls::fail = true;
+        {
+            ChainD c(W, D, 4 * stepBytes, 4 * stepBytes, MCMC::Chain::Detail::BlockMemory(&ProviderCalls::obtain, &ProviderCalls::release));
+            fill(c, 4, W, D);
+            CHECK((*c.getStepIteratorBegin())[5] == cell(0, 1, 2));
+        }
+        CHECK(ProviderCalls::released == 3);  // (heap blocks are not handed to the provider's release)
+        ProviderCalls::fail = false;
+    }
+    {
+        // The reference's own plumbing test at scale (/root/reference/test/sequential/InnerBenchmark/src/main.cpp:9-13,32:
+        // 2400 walkers x 4 parameters x 20 000 steps, chain budget 3.3e9 bytes, Mover::SequenceMove advancing parameter j
+        // of every walker by stepSize[j] = j + 1 per step, Movers/Diagnostic/SequenceMove.h): a walker-by-walker store
+        // as the reference's movers do it, then the known answer -- stored step k holds k * {1, 2, 3, 4} in every walker --
+        // through both iterators.  1.54 GB of chain, blocks of 256 MiB.
+        const int BW = 2400, BD = 4, steps = 20000;
+        ChainD c(BW, BD, 3300000000ULL);
+        std::vector<double> walkers((size_t)BW * BD, 0.0);
+        for (int w = 0; w < BW; ++w) c.storeWalker(w, walkers.data() + (size_t)w * BD);  // setInitialWalkerPos: step 0
+        CHECK(c.incrementChainStep() != IncrementStatus::EndOfChain);
+        bool full = false;
+        for (int s = 0; s < steps && !full; ++s)
+        {
+            for (int w = 0; w < BW; ++w)
+            {
+                double* x = walkers.data() + (size_t)w * BD;
+                for (int j = 0; j < BD; ++j) x[j] += (double)(j + 1);
+                c.storeWalker(w, x);
+            }
+            full = c.incrementChainStep() == IncrementStatus::EndOfChain;
+        }
+        CHECK(!full && c.getStoredStepCount() == steps + 1);
+        long k = 0, bad = 0;
+        for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != c.getStepIteratorEnd(); ++it, ++k)
+            for (int w = 0; w < BW; ++w)
+                for (int j = 0; j < BD; ++j) bad += (*it)[w * BD + j] != (double)k * (j + 1);
+        CHECK(k == steps + 1 && bad == 0);
+        long sets = 0;
+        bad = 0;
+        for (MCMC::Chain::ChainPsetIterator<double> pit = c.getPsetIteratorBegin(); pit != c.getPsetIteratorEnd(); ++pit, ++sets)
+            bad += (*pit)[3] != (double)(sets / BW) * 4.0;
+        CHECK(sets == (long)(steps + 1) * BW && bad == 0);
+        // the reference's test then reads nothing else; burning and slicing at this size: keep every 1000th step after 1
+        c.resetChainForSubSampling(1, 1000);
+        CHECK(c.getStoredStepCount() == 20);
+        k = 0;
+        for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != c.getStepIteratorEnd(); ++it, ++k)
+            CHECK((*it)[1] == (double)(1 + 1000 * k) * 2.0);
     }
     if (failures == 0) std::printf("chain_test OK\n");
     return failures == 0 ? 0 : 1;

@@ -90,10 +90,12 @@ struct CountingAction
 {
     long calls = 0;
     long lastSeenSteps = 0;
+    std::vector<long> seen;  // stored steps visible at every call
     void performAction(const Chain::ChainStepIterator<T>& start, const Chain::ChainStepIterator<T>& end)
     {
         ++calls;
         lastSeenSteps = end.stepIndex() - start.stepIndex();
+        seen.push_back(lastSeenSteps);
     }
 };
 
@@ -183,7 +185,31 @@ static void runCase(const Fixture<T>& f, Calc calc)
         CHECK(sampler.getAcceptedSteps() == f.acceptedTotal);
         CHECK(sampler.getAcceptanceFraction() == (T)f.acceptedTotal / (T)f.totalSteps);
         CHECK(action.calls == (long)f.steps * f.slicing);  // once per ensemble step (EnsembleSampler.h:356-359)
-        CHECK(action.lastSeenSteps == f.steps + 1);
+        // ... and BEFORE the chain moves on to the step being made (EnsembleSampler.h:291-293): the calls of stored step k
+        // (counting the initial placement as step 0) see k stored steps
+        CHECK(action.lastSeenSteps == f.steps);
+        bool ordered = action.seen.size() == (size_t)f.steps * f.slicing;
+        for (size_t i = 0; ordered && i < action.seen.size(); ++i) ordered = action.seen[i] == 1 + (long)(i / (size_t)f.slicing);
+        CHECK(ordered);
+    }
+    if (!Sel::drawsVary)
+    {
+        // the same ensemble through the split path: one rank of an RCCL communicator (all a one-GPU box has); several
+        // devices differ only in the number of ranks
+        MoverType mover(f.D, 0, calc);
+        Device::Placement where;
+        where.splitEnsemble = true;
+        ParallelEnsembleSampler<T, MoverType> sampler(0, 8, f.W, f.D, mover, 2147483648ULL, nullptr, where);
+        CHECK(sampler.deviceCount() == 1);
+        sampler.setSamplingMode(f.slicing, 0);
+        sampler.setInitialWalkerPos(pos.data(), logp.data());
+        CHECK(sampler.runMCMC(f.steps / 2));
+        CHECK(sampler.runMCMC(f.steps - f.steps / 2));
+        checkChain(sampler, f);
+        CHECK(sampler.getAcceptedSteps() == f.acceptedTotal);
+        std::uint64_t ties = 1, redraws = 1;
+        sampler.diagnostics(&ties, &redraws);
+        CHECK(ties == 0 && redraws == 0);
     }
     {
         // chain budget: room for 5 steps only -> runMCMC reports false when it fills (EnsembleSampler.h:293)

@@ -24,7 +24,7 @@ def test_exports_every_declared_symbol(lib):
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.mcmcpp_hip_abi_version() == 1
+    assert lib.mcmcpp_hip_abi_version() == 2
 
 
 def test_header_is_plain_c(tmp_path):

@@ -64,6 +64,102 @@ def test_sharded_handles_sharing_one_replica_follow_the_single_chain(W, D, calc,
         handles[0].run(1)              # a sharded handle is not driven by run()
 
 
+def _params(calc, D, rng):
+    if calc == po.CALC_DENSE_GAUSSIAN:
+        a = rng.standard_normal((D, D))
+        return (a @ a.T / D + np.eye(D)).ravel()
+    if calc == po.CALC_ROSENBROCK:
+        return np.array([1.0, 100.0, 0.05])
+    return None
+
+
+@pytest.mark.parametrize("W,D,calc", [(4096, 32, po.CALC_ISO_GAUSSIAN), (4096, 32, po.CALC_DENSE_GAUSSIAN), (2048, 64, po.CALC_DENSE_GAUSSIAN),
+                                      (1024, 7, po.CALC_ROSENBROCK)])
+@pytest.mark.parametrize("scheme", ["exchange_per_step", "exchange_per_half_step"])
+@pytest.mark.parametrize("slices", [1, 4])
+def test_split_ensemble_run_through_the_c_abi(monkeypatch, W, D, calc, scheme, slices):
+    """mcmcpp_hip_run on a handle with an RCCL communicator (one rank: all this box has): launches and ncclAllGather
+    calls enqueued by the library itself, stored steps, ensemble-wide accepted counts, get_state -- bit for bit the
+    oracle's chain.  `slices` > 1 steps the ensemble as that many ranks' slices, one launch each (the sliced kernels of
+    both schemes: a black walker's group repeating a red update that another rank owns)."""
+    monkeypatch.setenv("MCMCPP_HIP_COMM_FULL_STEP", "1" if scheme == "exchange_per_step" else "0")
+    monkeypatch.setenv("MCMCPP_HIP_COMM_EMULATE_RANKS", str(slices))
+    rng = np.random.default_rng(11)
+    params = _params(calc, D, rng)
+    orc = po.Oracle(W, D, calc, params, seed=9)
+    pos = po.init_positions(po.F64, W, D, salt=1)
+    logp = orc.logp(pos)
+    orc.set_state(pos, logp)
+    hip = capi.HipSampler(W, D, calc, params, seed=9, comm_world=1, comm_rank=0, comm_id=capi.comm_unique_id())
+    hip.set_state(pos, logp)
+    for n_saved, interval in ((3, 2), (1, 1), (2, 3)):  # (odd step counts: the live ensemble ends in the second buffer)
+        want_chain, want_acc = orc.run(n_saved, interval=interval)
+        chain, acc = hip.run(n_saved, interval=interval)
+        np.testing.assert_array_equal(acc, want_acc)
+        np.testing.assert_array_equal(chain, want_chain)
+        for got, want in zip(hip.get_state(), orc.get_state()):
+            np.testing.assert_array_equal(got, want)
+    c = hip.counters()
+    assert c["near_ties"] == 0 and c["redraws"] == 0 and c["ensemble_steps"] == 13
+    enq_ms, wall_ms, xchg_us = hip.last_run_host_timing()
+    assert 0 < enq_ms <= wall_ms and xchg_us >= 0
+
+
+def test_split_ensemble_config_is_checked():
+    cid = capi.comm_unique_id()
+    with pytest.raises(capi.HipError):  # W/2 must divide by the number of ranks
+        capi.HipSampler(4098, 8, po.CALC_ISO_GAUSSIAN, None, comm_world=2, comm_rank=0, comm_id=cid)
+    with pytest.raises(capi.HipError):  # rank outside the communicator
+        capi.HipSampler(4096, 8, po.CALC_ISO_GAUSSIAN, None, comm_world=2, comm_rank=2, comm_id=cid)
+    with pytest.raises(capi.HipError):  # a shard that is not the rank's slice
+        capi.HipSampler(4096, 8, po.CALC_ISO_GAUSSIAN, None, comm_world=1, comm_rank=0, comm_id=cid, shard_begin=0, shard_count=512)
+    with pytest.raises(capi.HipError):  # neither an id nor a communicator
+        capi.HipSampler(4096, 8, po.CALC_ISO_GAUSSIAN, None, comm_world=1, comm_rank=0)
+
+
+def test_config5_full_size_split_run_single_rank():
+    """BASELINE config 5's ensemble (131 072 x 64) through the split path of the C ABI on the one GPU this box has:
+    3 steps against the multi-threaded oracle (half-step scheme: the slice is the whole half), then as 8 ranks'
+    slices of 8 192 walkers per colour -- the per-GPU launches of the 8-GPU job, one exchange per ensemble step."""
+    W, D = 131072, 64
+    orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=0)
+    pos = po.init_positions(po.F64, W, D, salt=0)
+    logp = orc.logp(pos)
+    orc.set_state(pos, logp)
+    want_chain, want_acc = orc.run(3, mode=po.MODE_COUNTER, threads=8)
+    for env in ({}, {"MCMCPP_HIP_COMM_EMULATE_RANKS": "8", "MCMCPP_HIP_FULL_STEP_MAX_WALKERS": "262144"}):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, comm_world=1, comm_rank=0, comm_id=capi.comm_unique_id())
+        finally:
+            for k in env:
+                del os.environ[k]
+        hip.set_state(pos, logp)
+        chain, acc = hip.run(3)
+        np.testing.assert_array_equal(acc, want_acc)
+        np.testing.assert_array_equal(chain, want_chain)
+        for got, want in zip(hip.get_state(), orc.get_state()):
+            np.testing.assert_array_equal(got, want)
+        hip.close()
+
+
+def test_whole_ensemble_handle_on_the_legacy_default_stream():
+    """hip_stream = NULL with MCMCPP_HIP_FLAG_CALLER_STREAM is the legacy default stream, on which HIP cannot capture
+    graphs: run() must fall back to plain launches instead of failing."""
+    W, D = 2048, 8
+    orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=2)
+    pos = po.init_positions(po.F64, W, D, salt=4)
+    logp = orc.logp(pos)
+    orc.set_state(pos, logp)
+    hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=2, hip_stream=0)
+    hip.set_state(pos, logp)
+    want_chain, want_acc = orc.run(5, interval=2)
+    chain, acc = hip.run(5, interval=2)
+    np.testing.assert_array_equal(acc, want_acc)
+    np.testing.assert_array_equal(chain, want_chain)
+
+
 _SINGLE_RANK = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
