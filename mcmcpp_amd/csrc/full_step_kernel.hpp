@@ -63,14 +63,15 @@ __host__ __device__ inline uint32_t full_step_bits(uint32_t half_bits, int pos_p
 // and second half of those walkers, 2 and 3 the black ones
 template <class T>
 __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, const RunInfo* run_ptr,
-                                                    bool block_barrier, DrawRec<T>* dn_red, int n, int sh_begin, int sh_count, int wpb, int which, int lane)
+                                                    bool block_barrier, DrawRec<T>* dn_red, int n, int sh_begin, int sh_count, int wpb, int which, int lane,
+                                                    int run_behind_ctl = -1)
 {
     const int black = kFullDrawWaves == 4 ? which >> 1 : which, half = kFullDrawWaves == 4 ? (which & 1) : 0;
     const int h0 = kFullDrawWaves == 4 ? (wpb + 1) / 2 : wpb;  // walkers of the first half
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
     // (the first of them also forwards this launch's slice of the last stored step: trickle_stored_step)
     draw_wave_body<T, 1>(a, tab, ctl_ptr, block_barrier, dst, dst, 1, sh_begin, sh_count, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0,
-                         which == 0 ? run_ptr : nullptr);
+                         which == 0 ? run_ptr : nullptr, which == 0 ? run_behind_ctl : -1);
 }
 
 // Both full-step kernels update walkers [sh_begin, sh_begin + sh_count) of EACH colour (the whole halves, or the slice
@@ -79,7 +80,7 @@ __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, co
 // 16 preloaded dwords; what they displaced is derived: the accepted counters lie right behind the two log-posterior
 // buffers ([2][W] elements, then [W] counters: one allocation), and the run record kRunBehindCtlBytes behind the
 // first control record.
-constexpr int kRunBehindCtlBytes = 256;
+// (run_record_behind, stretch_kernel.hpp)
 
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
@@ -363,14 +364,13 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // (log-posteriors [2][W] and accepted counters [W] are one allocation: the counters' address is derived)
     uint32_t* const h_n_accept = reinterpret_cast<uint32_t*>(hot_logp_a + 4 * (size_t)h_n);
     const int sh_begin = hot_sh_begin, sh_count = hot_sh_count;
-    // (the run record lies kRunBehindCtlBytes behind the first of the two control records; this launch reads record h_flip)
-    const RunInfo* const hot_run = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(hot_ctl_in - (h_flip ? 1 : 0)) + kRunBehindCtlBytes);
 
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
-        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, false, dn_red, h_n, sh_begin, sh_count,
-                               kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane);
+        // (the run record's address is derived from the control record's, where it is needed: run_record_behind)
+        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, nullptr, false, dn_red, h_n, sh_begin, sh_count,
+                               kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -435,7 +435,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
     StepCtl ctl;
     RunInfo run;
-    load_records_and_warm_args<T>(hot_ctl_in, hot_run, ctl, run);
+    load_records_and_warm_args<T>(hot_ctl_in, run_record_behind(hot_ctl_in, h_flip ? 1 : 0), ctl, run);
     if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run);
     long long save_slot = -1;
     if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;

@@ -471,6 +471,18 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
     }
 }
 
+// The run record lies kRunBehindCtlBytes behind the first of the two control records (one allocation).  A kernel short
+// of preloaded arguments derives its address from the control record it reads (record `which`: 0 or 1).  The asm pins
+// the derivation where it is written: the compiler would otherwise hoist it -- and the wait for the kernarg load the
+// control record's address comes from -- to the top of the kernel.
+constexpr int kRunBehindCtlBytes = 256;
+__device__ __forceinline__ const RunInfo* run_record_behind(const StepCtl* ctl_in, int which)
+{
+    unsigned long long c = (unsigned long long)ctl_in;
+    asm volatile("" : "+s"(c)::"memory");
+    return reinterpret_cast<const RunInfo*>(c - (unsigned long long)which * sizeof(StepCtl) + (unsigned long long)kRunBehindCtlBytes);
+}
+
 // Hot scalars of a launch, packed so that the arguments every wavefront needs before its first memory
 // access fit the 16 dwords the command processor preloads into SGPRs (-amdgpu-kernarg-preload-count=16);
 // everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
@@ -540,7 +552,7 @@ template <class T, int MAXR>
 __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, bool block_barrier,
                                                DrawRec<T>* write0, DrawRec<T>* write1, int colours, int shard_begin, int shard_count,
                                                int group_first, int group_walkers, int lane, bool black_only = false,
-                                               const RunInfo* trickle_run = nullptr)
+                                               const RunInfo* trickle_run = nullptr, int run_behind_ctl = -1)
 {
 #ifdef MCMCPP_STAMPS
     unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -582,6 +594,10 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const J
     StepCtl ctl;
     {
         RunInfo run;  // (only wanted when this wavefront also forwards stored steps; otherwise the control record twice)
+        // run_behind_ctl >= 0: the run record's address follows from the control record's (run_record_behind); derived
+        // HERE, behind the table loads above -- the control record's address is not among the preloaded arguments, and
+        // an address computed at the top of the kernel puts that cold kernarg miss in front of every wavefront's first loads
+        if (run_behind_ctl >= 0) trickle_run = run_record_behind(ctl_ptr, run_behind_ctl);
         load_records_and_warm_args<T>(ctl_ptr, trickle_run != nullptr ? trickle_run : reinterpret_cast<const RunInfo*>(ctl_ptr), ctl, run);
         if (trickle_run != nullptr) trickle_stored_step(run, ctl, lane);
     }
