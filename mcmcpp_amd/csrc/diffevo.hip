@@ -1,11 +1,13 @@
-// diffevo.hip -- host side and stream-planning kernels of Mover::DifferentialEvolution on gfx950 (SURVEY.md 8f row f3;
-// reference MCMCpp/Movers/DifferentialEvolution.h:80-112 inside EnsembleSampler::performStep, EnsembleSampler.h:342-354).
-// See diffevo_kernel.hpp for the scheme: plan (parallel) -> update (a few dozen sequential steps from LDS, then parallel),
-// two launches per half-step on one stream, the stream position and the error flag travelling in device memory.
+// diffevo.hip -- host side of Mover::DifferentialEvolution on gfx950 (reference
+// MCMCpp/Movers/DifferentialEvolution.h:80-112 inside EnsembleSampler::performStep, EnsembleSampler.h:342-354).
+// See diffevo_kernel.hpp for the scheme: ONE launch per half-step (update of half-step h beside the stream planning of
+// h + 1 and h + 2), replayed from a hipGraph; the stream position, the error flags and the per-run counters travel in
+// device memory.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -18,74 +20,6 @@ using namespace mcmcpp;
 
 namespace
 {
-// Would an update of walker k that starts r draws late (r = 0..kDeMaxShift) throw draws away?  One wavefront per walker:
-// lane j makes raw draw j behind (D+3)k (one table jump from the walker's base state), neighbouring lanes compare, and
-// for the rare walker where the answer is yes for some r, lane r walks the update that starts at draw r and the table
-// extra[r] goes to the candidate list.
-__global__ void __launch_bounds__(256)
-de_plan_kernel(DeCtl* ctl, DeCand* cand, const Affine128* jump_hi, const Affine128* jump_lo, const Affine128* jump_small, uint64_t threshold, int n)
-{
-    __shared__ uint64_t sh_raw[4][64];
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const bool pow2 = (n & (n - 1)) == 0;
-    const U128 state = ctl->state;
-    const Affine128 j_draw = jump_small[(lane < kDeRaw ? lane : kDeRaw - 1) + 1];
-    const int waves = gridDim.x * 4;
-    for (int k = blockIdx.x * 4 + wib; k < n; k += waves)
-    {
-        const U128 base = apply(jump_lo[k & 255], apply(jump_hi[k >> 8], state));
-        const uint64_t raw = pcg_output(apply(j_draw, base));
-        const uint64_t nxt = __shfl_down(raw, 1);
-        // clean(j): draws j and j+1 are both kept and name different walkers: an update starting at j throws nothing away
-        const bool bad = lane <= kDeMaxShift && (raw < threshold || nxt < threshold || de_bounded(raw, n, pow2) == de_bounded(nxt, n, pow2));
-        if (__ballot(bad) == 0) continue;
-        uint32_t slot = 0;
-        if (lane == 0) slot = atomicAdd(&ctl->cand_count, 1u);
-        slot = __shfl(slot, 0);
-        if (slot >= (uint32_t)kDeMaxCand)
-        {
-            if (lane == 0) atomicOr(&ctl->error, kDeErrCand);
-            continue;
-        }
-        // (one wavefront: its LDS accesses execute in order; the fences keep the compiler from moving them)
-        sh_raw[wib][lane] = raw;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane <= kDeMaxShift)
-        {
-            // DifferentialEvolution.h:83-87 from draw `lane` on
-            const uint64_t* rw = sh_raw[wib];
-            int at = lane;
-            const int end = lane + kDeWindow;
-            uint64_t v;
-            do v = rw[at++];
-            while (v < threshold && at < end);
-            const uint32_t ind1 = de_bounded(v, n, pow2);
-            uint32_t ind2 = ind1;
-            bool overrun = v < threshold;
-            do
-            {
-                if (at >= end)
-                {
-                    overrun = true;
-                    break;
-                }
-                do v = rw[at++];
-                while (v < threshold && at < end);
-                if (v < threshold) overrun = true;
-                ind2 = de_bounded(v, n, pow2);
-            } while (ind2 == ind1);
-            // (an overrun is an error only if the walk in the update kernel comes through this start)
-            cand[slot].extra[lane] = overrun ? (uint8_t)kDeOverrun : (uint8_t)(at - lane - 2);
-        }
-        if (lane == 0) cand[slot].k = (uint32_t)k;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-
 template <class T>
 class DeSampler final : public mcmcpp_hip_sampler
 {
@@ -136,8 +70,32 @@ public:
         HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
         HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
-        HIP_TRY(hipMalloc(&d_ctl, sizeof(DeCtl) * 2));
-        HIP_TRY(hipMalloc(&d_cand, sizeof(DeCand) * kDeMaxCand));
+        HIP_TRY(hipMalloc(&d_ctl, sizeof(DeCtl) * 4));
+        HIP_TRY(hipMalloc(&d_shared, sizeof(DeShared)));
+        HIP_TRY(hipMalloc(&d_cand, sizeof(DeCand) * 2 * kDeMaxCand));
+        HIP_TRY(hipMalloc(&d_resolved, sizeof(DeResolved) * 2));
+        HIP_TRY(hipMemset(d_resolved, 0, sizeof(DeResolved) * 2));
+        HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * (size_t)n));
+        HIP_TRY(hipMalloc(&d_run, sizeof(DeRunInfo)));
+        HIP_TRY(hipMalloc(&d_step, sizeof(DeStepCtl) * 2));
+        HIP_TRY(hipMemset(d_shared, 0, sizeof(DeShared)));
+        HIP_TRY(hipMemset(d_cand, 0, sizeof(DeCand) * 2 * kDeMaxCand));
+        for (int k = 0; k < 2; ++k)
+        {
+            HIP_TRY(hipEventCreate(&ev_t0[k]));
+            HIP_TRY(hipEventCreate(&ev_t1[k]));
+        }
+        // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
+        {
+            // MCMCPP_HIP_DE_FIND_WALKERS: batches of kDeFindBatch walkers one finder wavefront looks at (read once, here)
+            const char* v = std::getenv("MCMCPP_HIP_DE_FIND_WALKERS");
+            knob_walkers_per_find_wave = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 1;
+            if (knob_walkers_per_find_wave < 1) knob_walkers_per_find_wave = 1;
+            v = std::getenv("MCMCPP_HIP_DE_DEBUG");
+            knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
+        }
+        graph_steps = c.graph_steps == 0 ? 128 : c.graph_steps;
+        if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
         HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
         if (c.calc_params_len > 0)
@@ -188,10 +146,11 @@ public:
         HIP_TRY(hipMemcpyAsync(d_logp, logp, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
         HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(Diag), stream));
-        DeCtl c[2];
+        DeCtl c[4];
         std::memset(c, 0, sizeof c);
         c[0].state = state0;
         HIP_TRY(hipMemcpyAsync(d_ctl, c, sizeof c, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_shared, 0, sizeof(DeShared), stream));
         HIP_TRY(hipStreamSynchronize(stream));
         half_steps = 0;
         steps_since_reset = 0;
@@ -201,6 +160,28 @@ public:
 
     // EnsembleSampler::runMCMC (EnsembleSampler.h:284-310): interval-1 unsaved ensemble steps, one saved, n_saved times
     int run(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step) override
+    {
+        run_touched = false;
+        const int rc = run_steps(n_saved, interval, chain_out, accepted_per_step);
+        if (rc != MCMCPP_HIP_OK && run_touched)
+        {
+            // launches went out and the call failed: the walkers are ahead of the host's counters (and the stream may
+            // be left capturing) -- nothing on the device can be trusted until the next set_state
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
+            {
+                hipGraph_t g = nullptr;
+                (void)hipStreamEndCapture(stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+            }
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+            have_state = false;
+        }
+        return rc;
+    }
+
+    int run_steps(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
     {
         if (!have_state) return fail(MCMCPP_HIP_E_STATE, "run: set_state has not been called");
         if (n_saved < 0 || interval < 1) return fail(MCMCPP_HIP_E_ARG, "run: n_saved >= 0 and interval >= 1 required");
@@ -243,19 +224,24 @@ public:
             HIP_TRY(hipMalloc(&d_acc, sizeof(uint32_t) * (size_t)acc_piece));
             acc_count = (size_t)acc_piece;
         }
-        DeArgs<T> a;
+        DeArgs<T>& a = args;
         std::memset(&a, 0, sizeof a);
         a.pos = d_pos;
         a.logp = d_logp;
         a.n_accept = d_nacc;
         a.calc_params = d_params;
+        a.ctl = d_ctl;
+        a.shared = d_shared;
         a.cand = d_cand;
+        a.resolved = d_resolved;
+        a.recs = d_recs;
+        a.run = d_run;
+        a.step_ctl = d_step;
         a.half_jump = half_jump;
         a.jump_hi = d_jump_hi;
         a.jump_lo = d_jump_lo;
         a.jump_small = d_jump_small;
         a.diag = d_diag;
-        a.chain = d_chain;
         a.threshold = threshold;
         a.inc = inc;
         a.gamma = gamma;
@@ -265,34 +251,47 @@ public:
         a.n = n;
         a.dims = D;
         a.vec_ok = vec_ok;
-        // a wavefront per walker, at most 8 wavefronts per SIMD's worth of workgroups
-        const unsigned plan_grid = (unsigned)(n / 4 < 2048 ? (n + 3) / 4 : 2048);
         const int per_block = (64 / lpw) * kWavesPerBlock;
-        const unsigned update_grid = (unsigned)((n + per_block - 1) / per_block);
+        update_blocks = (n + per_block - 1) / per_block;
+        record_blocks = (n + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
+        // finders: a wavefront per walker, about eight walkers per wavefront
+        find_blocks = (n + kDeFindBatch * knob_walkers_per_find_wave * kWavesPerBlock - 1) / (kDeFindBatch * knob_walkers_per_find_wave * kWavesPerBlock);
+        if (find_blocks > 4096) find_blocks = 4096;
+        if (find_blocks < 1) find_blocks = 1;
+
+        // Priming: the planners run one half-step (records) and two half-steps (candidates) ahead of the updates.  Two
+        // planning-only launches bring them there from the stream position the ring holds for the coming half-step.
+        run_touched = true;
+        {
+            // (the candidate counters and the finders' tickets; the error flags stay)
+            HIP_TRY(hipMemsetAsync(d_shared, 0, offsetof(DeShared, error), stream));
+            HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(d_shared) + offsetof(DeShared, finished), 0, sizeof(uint32_t) * 4, stream));
+        }
+        launch_step((int)((half_steps + 2) & 3), /*with_update=*/false, /*with_records=*/false);  // candidates of the coming half-step
+        launch_step((int)((half_steps + 3) & 3), false, true);                                     // its records, candidates of the next
+        HIP_TRY(hipGetLastError());
+
+        double gpu_ms = 0.0;
         for (int64_t first = 0; first < n_saved; first += piece)
         {
             const int64_t now = n_saved - first < piece ? n_saved - first : piece;
             if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)(now * interval) * kDeAccSlots, stream));
-            for (int64_t s = 0; s < now; ++s)
-                for (int32_t j = 0; j < interval; ++j)
-                {
-                    const bool save = chain_out && j == interval - 1;
-                    for (int color = 0; color < 2; ++color)
-                    {
-                        DeCtl* cur = d_ctl + (half_steps & 1);
-                        DeCtl* nxt = d_ctl + ((half_steps + 1) & 1);
-                        hipLaunchKernelGGL(de_plan_kernel, dim3(plan_grid), dim3(256), 0, stream, cur, d_cand, d_jump_hi, d_jump_lo, d_jump_small, threshold, n);
-                        a.ctl = cur;
-                        a.ctl_next = nxt;
-                        a.color = color;
-                        a.save_slot = save ? (long long)s : -1;
-                        a.accepted = accepted_per_step ? d_acc + (s * interval + j) * kDeAccSlots : nullptr;
-                        update_fn(a, update_grid, stream);
-                        ++half_steps;
-                        last_launches += 2;
-                    }
-                }
-            HIP_TRY(hipGetLastError());
+            {
+                DeRunInfo ri;
+                std::memset(&ri, 0, sizeof ri);
+                ri.chain = chain_out ? d_chain : nullptr;
+                ri.accepted = accepted_per_step ? d_acc : nullptr;
+                ri.interval = interval;
+                DeStepCtl sc[2];
+                std::memset(sc, 0, sizeof sc);
+                HIP_TRY(hipMemcpyAsync(d_run, &ri, sizeof ri, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_step, sc, sizeof sc, hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipStreamSynchronize(stream));  // (the sources are on this stack frame)
+            }
+            HIP_TRY(hipEventRecord(ev_t0[0], stream));
+            int rc = enqueue_steps(now * interval);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_t1[0], stream));
             if (chain_out)
                 HIP_TRY(hipMemcpyAsync(static_cast<char*>(chain_out) + (size_t)first * step_bytes, d_chain, (size_t)now * step_bytes, hipMemcpyDeviceToHost, stream));
             if (accepted_per_step)
@@ -301,6 +300,12 @@ public:
                 HIP_TRY(hipMemcpyAsync(acc_host.data(), d_acc, sizeof(uint32_t) * acc_host.size(), hipMemcpyDeviceToHost, stream));
             }
             HIP_TRY(hipStreamSynchronize(stream));
+            {
+                float ms = 0.f;
+                HIP_TRY(hipEventElapsedTime(&ms, ev_t0[0], ev_t1[0]));
+                gpu_ms += ms;
+            }
+            if (chain_out) publish_stored(first + now);
             if (accepted_per_step)
                 for (int64_t e = 0; e < now * interval; ++e)
                 {
@@ -310,17 +315,82 @@ public:
                 }
         }
         steps_since_reset += (uint64_t)total;
-        DeCtl c;
-        HIP_TRY(hipMemcpy(&c, d_ctl + (half_steps & 1), sizeof c, hipMemcpyDeviceToHost));
-        last_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (c.error)
+        DeShared sh;
+        HIP_TRY(hipMemcpy(&sh, d_shared, sizeof sh, hipMemcpyDeviceToHost));
+        last_ms = gpu_ms;  // GPU time of the step launches between HIP events on the launch stream (transfers excluded)
+        last_launches = 2 * total;
+        host_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (sh.error)
         {
             have_state = false;
             return fail(MCMCPP_HIP_E_UNSUPPORTED,
                         "differential evolution: the random stream could not be followed (flags %u: 1 = more than %d draws thrown away in one "
                         "half-step, 2 = more than %d candidates, 4 = one update threw away more than %d draws); the state is undefined, call set_state",
-                        c.error, kDeMaxShift, kDeMaxCand, kDeWindow - 2);
+                        sh.error, kDeMaxShift, kDeMaxCand, kDeWindow - 2);
         }
+        return MCMCPP_HIP_OK;
+    }
+
+    // one launch: the update of half-step `h4` (mod 4) beside the planning of the two half-steps behind it
+    void launch_step(int h4, bool with_update, bool with_records)
+    {
+        DeArgs<T> a = args;
+        a.half_step_mod4 = h4;
+        a.update_blocks = with_update ? update_blocks : 0;
+        a.record_blocks = with_records ? record_blocks : 0;
+        unsigned grid = (unsigned)(a.update_blocks + a.record_blocks + find_blocks);
+        // timing diagnostics only (MCMCPP_HIP_DE_DEBUG; the chain is wrong): 1 = regular launches without planners, 2 = without updates
+        if (with_update && knob_debug == 1) grid = (unsigned)a.update_blocks;
+        if (with_update && knob_debug == 2) a.update_blocks = 0, grid = (unsigned)(a.record_blocks + find_blocks);
+        update_fn(a, grid, stream);
+    }
+
+    // hipGraph of `steps` ensemble steps that start at half-step residue `r0` (0 or 2)
+    int graph_for(int steps, int r0, hipGraphExec_t* out)
+    {
+        const size_t key = (size_t)steps * 2 + (size_t)(r0 >> 1);
+        if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
+        if (!graph_cache[key])
+        {
+            hipGraph_t g = nullptr;
+            HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
+            for (int s = 0; s < steps; ++s)
+                for (int c = 0; c < 2; ++c) launch_step((r0 + 2 * s + c) & 3, true, true);
+            HIP_TRY(hipStreamEndCapture(stream, &g));
+            hipGraphExec_t ex = nullptr;
+            HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+            HIP_TRY(hipGraphDestroy(g));
+            graph_cache[key] = ex;
+        }
+        *out = graph_cache[key];
+        return MCMCPP_HIP_OK;
+    }
+
+    int enqueue_steps(int64_t steps)
+    {
+        int64_t left = steps;
+        while (left > 0)
+        {
+            const int r0 = (int)(half_steps & 3);
+            if (graph_steps >= 1)
+            {
+                const int now = (int)(left < graph_steps ? left : graph_steps);
+                hipGraphExec_t ex = nullptr;
+                int rc = graph_for(now, r0, &ex);
+                if (rc) return rc;
+                HIP_TRY(hipGraphLaunch(ex, stream));
+                half_steps += 2 * (uint64_t)now;
+                left -= now;
+            }
+            else
+            {
+                launch_step(r0, true, true);
+                launch_step((r0 + 1) & 3, true, true);
+                half_steps += 2;
+                left -= 1;
+            }
+        }
+        HIP_TRY(hipGetLastError());
         return MCMCPP_HIP_OK;
     }
 
@@ -370,7 +440,7 @@ public:
         if (redraws)
         {
             DeCtl c;
-            HIP_TRY(hipMemcpy(&c, d_ctl + (half_steps & 1), sizeof c, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(&c, d_ctl + (half_steps & 3), sizeof c, hipMemcpyDeviceToHost));
             *redraws = c.extra_total;  // every draw thrown away so far (bounded_rand, ind2 == ind1)
         }
         return MCMCPP_HIP_OK;
@@ -432,9 +502,16 @@ private:
     {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_cand, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc};
+        for (hipGraphExec_t ex : graph_cache)
+            if (ex) (void)hipGraphExecDestroy(ex);
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_cand, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_run, d_step, d_resolved};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
+        for (int k = 0; k < 2; ++k)
+        {
+            if (ev_t0[k]) (void)hipEventDestroy(ev_t0[k]);
+            if (ev_t1[k]) (void)hipEventDestroy(ev_t1[k]);
+        }
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 
@@ -448,6 +525,16 @@ private:
     uint32_t *d_nacc = nullptr, *d_acc = nullptr;
     Diag* d_diag = nullptr;
     DeCtl* d_ctl = nullptr;
+    DeShared* d_shared = nullptr;
+    DeResolved* d_resolved = nullptr;
+    DeRec<T>* d_recs = nullptr;
+    DeRunInfo* d_run = nullptr;
+    DeStepCtl* d_step = nullptr;
+    DeArgs<T> args;
+    int update_blocks = 0, record_blocks = 0, find_blocks = 1, graph_steps = 128, knob_walkers_per_find_wave = 2, knob_debug = 0;
+    bool run_touched = false;
+    hipEvent_t ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
+    std::vector<hipGraphExec_t> graph_cache;
     DeCand* d_cand = nullptr;
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_jump_small = nullptr;
     size_t chain_bytes = 0, acc_count = 0;

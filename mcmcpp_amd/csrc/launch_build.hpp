@@ -67,7 +67,7 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_de(const DeArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    hipLaunchKernelGGL((de_update_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a);
+    hipLaunchKernelGGL((de_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a);
 }
 
 template <class T, class Calc, int LPWLOG, int EPLSHIFT>

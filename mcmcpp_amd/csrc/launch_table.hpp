@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D43000Bu;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D43000Cu;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -33,7 +33,7 @@ struct LaunchTable
     // (generic) or 32 per colour (matrix-core variant)
     HalfStepFn full_step[kLpwLevels][kMaxEplShift];
     HalfStepFn full_step_mc[kLpwLevels][kMaxEplShift];
-    // Mover::DifferentialEvolution (diffevo_kernel.hpp): one launch updates a whole half
+    // Mover::DifferentialEvolution (diffevo_kernel.hpp): one launch updates a whole half and plans the stream of the next two
     typedef void (*DeFn)(const DeArgs<T>&, unsigned grid, hipStream_t);
     DeFn de_update[kLpwLevels][kMaxEplShift];
 };

@@ -24,6 +24,7 @@ using arrow_vendored::pcg64;
 #include "EnsembleSampler.h"
 #include "Movers/StretchMove.h"
 #include "Movers/DifferentialEvolution.h"
+#include "Movers/WalkMove.h"
 #include "ParallelEnsembleSampler.h"
 #include "Common/SkewedGaussian.h"
 #include "Analysis/CovarianceMatrix.h"
@@ -89,6 +90,20 @@ int runDiffEvo(Calc& calc, int W, int D, int seed, const T* initPos, const T* in
                                   totalAfterCall, storedSteps, seconds);
 }
 
+/* Mover::WalkMove with the reference test's 6 sampled walkers (test/sequential/SkewedGaussian/WalkMove/src/main.cpp:35):
+ * timed only -- DESIGN.md section 7 records why this mover has no device kernel */
+template <class T, class Calc>
+int runWalk(Calc& calc, int W, int D, int seed, const T* initPos, const T* initLogp, int nCalls,
+            int stepsPerCall, int slicing, T* chainOut, long long chainCapacitySteps,
+            unsigned long long* acceptedAfterCall, unsigned long long* totalAfterCall, int* storedSteps,
+            double* seconds)
+{
+    typedef MCMC::Mover::WalkMove<T, Calc> MoverType;
+    MoverType mover(D, seed, calc, 6);
+    return runMover<T, MoverType>(mover, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing, chainOut, chainCapacitySteps, acceptedAfterCall,
+                                  totalAfterCall, storedSteps, seconds);
+}
+
 template <class T, class Calc>
 int runParallel(Calc& calc, int threads, int W, int D, int seed, const T* initPos, const T* initLogp, int nSteps,
                 double* seconds, double* acceptanceFraction)
@@ -111,6 +126,9 @@ int dispatch(int calcId, int threads, int alphaCode, int W, int D, const T* para
              unsigned long long* acc, unsigned long long* tot, int* stored, double* seconds, double* fraction)
 {
 #define MCMCPP_REF_GO(CALC)                                                                                        \
+    if (threads <= 0 && alphaCode == 3)                                                                            \
+        return runWalk<T, decltype(CALC)>(CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing,      \
+                                          chainOut, chainCapacitySteps, acc, tot, stored, seconds);                \
     if (threads <= 0 && alphaCode == 2)                                                                            \
         return runDiffEvo<T, decltype(CALC)>(CALC, W, D, seed, initPos, initLogp, nCalls, stepsPerCall, slicing,   \
                                              chainOut, chainCapacitySteps, acc, tot, stored, seconds);             \
@@ -202,7 +220,8 @@ extern "C"
 {
 /* threads <= 0: MCMC::EnsembleSampler; threads >= 1: MCMC::ParallelEnsembleSampler (timing only:
  * it is non-deterministic above one thread, ParallelEnsembleSampler.h:71-76).
- * alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>; 2: Mover::DifferentialEvolution.
+ * alpha_code 0: StretchMove's default GwDistribution<T,2,1>; 1: GwDistribution<T,3,2>; 2: Mover::DifferentialEvolution;
+ * 3: Mover::WalkMove with 6 sampled walkers (timing only).
  * dtype 0 = double, 1 = float.  chain_out holds up to chain_capacity_steps steps of W*D values
  * (chain step 0 is the initial placement, EnsembleSampler.h:228-229). */
 int ref_run(int dtype, int threads, int alpha_code, int W, int D, int calc_id, const void* params, int seed, const void* init_pos,

@@ -30,8 +30,17 @@ def main():
     dev = time.perf_counter() - t0
     done = (steps // 100) * 100
     c = s.counters()
-    line = "differential evolution %d x %d dense Gaussian: device %.3e walker-steps/s (%.1f us per ensemble step, 4 launches), acceptance %.3f, " \
-           "%d draws thrown away in %d half-steps" % (W, D, W * done / dev, dev / done * 1e6, acc.sum() / (W * done), c["redraws"], 2 * (done + 50))
+    gpu_ms, launches = s.last_run_timing()
+    # algorithmic bytes of one DifferentialEvolution update (DifferentialEvolution.h:80-112): own row + two partner rows + own
+    # log-posterior read, row + log-posterior written = (4D + 2) * 8 bytes (1 040 at D = 32); one launch = one half-step
+    bytes_per_launch = (W // 2) * (4 * D + 2) * 8
+    us_per_launch = gpu_ms * 1e3 / launches
+    achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    line = "differential evolution %d x %d dense Gaussian: device %.3e walker-steps/s (%.2f us per ensemble step by the wall clock incl. the " \
+           "stored steps' download; %.2f us per launch = half-step by HIP events, 2 launches per step), acceptance %.3f, " \
+           "%d draws thrown away in %d half-steps; roofline: %.0f GB/s algorithmic = %.3f of 8000 (de_step_kernel, %d B per update)" \
+           % (W, D, W * done / dev, dev / done * 1e6, us_per_launch, acc.sum() / (W * done), c["redraws"], 2 * (done + 50), achieved,
+              achieved / 8000.0, (4 * D + 2) * 8)
     cpu_steps = max(1, min(30, (30 * 16384) // W))
     orc = po.Oracle(W, D, po.CALC_DENSE_GAUSSIAN, P, seed=0, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
     orc.set_state(pos, lp)
