@@ -104,6 +104,15 @@ typedef struct mcmcpp_hip_config {
     const void* comm_id;     /* MCMCPP_HIP_COMM_ID_BYTES bytes made by mcmcpp_hip_comm_unique_id on one rank and handed to
                                 all ranks by the caller's own means (file, MPI, torch.distributed ...), or NULL */
     void* comm;              /* or: an existing ncclComm_t of comm_world ranks on this handle's device (borrowed) */
+    /* Independent ensembles ("chains") stepped by the same kernel launches -- what several EnsembleSampler objects with
+     * seeds randSeed, randSeed + 1, ... would compute one after the other (BASELINE config 4 on one GPU).  Chain k is an
+     * ensemble of num_walkers walkers of its own, seeded with seed + k on the same stream.  0 or 1: one ensemble.  With
+     * K = num_chains > 1 every array argument gains a leading chain dimension: set_state positions[K][W][D], logp[K][W];
+     * run chain_out[K][n_saved][W][D] (chain k's stored steps are contiguous, like that sampler's own Chain),
+     * accepted_per_step[K][steps]; get_state likewise.  Counters are summed over the chains.  Needs ensembles small
+     * enough to be stepped with one launch per ensemble step (W <= 32768), whole on one device; at most 16 chains. */
+    int32_t num_chains;
+    int32_t reserved0;
 } mcmcpp_hip_config;
 
 #define MCMCPP_HIP_COMM_ID_BYTES 128

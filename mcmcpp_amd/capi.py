@@ -36,7 +36,7 @@ class Config(C.Structure):
                 ("gw_alpha_num", C.c_int32), ("gw_alpha_den", C.c_int32),
                 ("device_positions", C.c_void_p), ("hip_stream", C.c_void_p), ("flags", C.c_uint32),
                 ("mover", C.c_uint32), ("comm_world", C.c_int32), ("comm_rank", C.c_int32), ("comm_id", C.c_void_p),
-                ("comm", C.c_void_p)]
+                ("comm", C.c_void_p), ("num_chains", C.c_int32), ("reserved0", C.c_int32)]
 
 FLAG_CALLER_STREAM = 1
 COMM_ID_BYTES = 128
@@ -170,10 +170,11 @@ class HipSampler:
 
     def __init__(self, W, D, calc_id, params=None, seed=0, stream=0, dtype=F64, device=-1, shard_begin=0,
                  shard_count=0, graph_steps=0, device_positions=None, hip_stream=None, alpha=(2, 1), mover=0,
-                 comm_world=0, comm_rank=0, comm_id=None, comm=None):
+                 comm_world=0, comm_rank=0, comm_id=None, comm=None, num_chains=0):
         """comm_world >= 1: this handle is rank comm_rank of a split ensemble (comm_id: the 128 bytes of comm_unique_id(),
         the same on all ranks; or comm: an existing ncclComm_t as an integer); run() then steps the split ensemble."""
         self.W, self.D, self.dtype = W, D, dtype
+        self.K = num_chains if num_chains > 1 else 1  # independent ensembles stepped together (leading array dimension)
         self.np_t = np_dtype(dtype)
         self.params = None if params is None else np.ascontiguousarray(params, dtype=self.np_t).ravel()
         self._comm_id = None if comm_id is None else C.create_string_buffer(bytes(comm_id), COMM_ID_BYTES)
@@ -181,7 +182,8 @@ class HipSampler:
                           _ptr(self.params), seed & (2**64 - 1), stream & (2**64 - 1), device, shard_begin,
                           shard_count, graph_steps, alpha[0], alpha[1], device_positions,
                           0 if hip_stream is None else hip_stream, 0 if hip_stream is None else FLAG_CALLER_STREAM, mover,
-                          comm_world, comm_rank, None if self._comm_id is None else C.cast(self._comm_id, C.c_void_p), comm)
+                          comm_world, comm_rank, None if self._comm_id is None else C.cast(self._comm_id, C.c_void_p), comm,
+                          num_chains, 0)
         self.h = C.c_void_p()
         rc = lib().mcmcpp_hip_create(C.byref(self.cfg), C.byref(self.h))
         if rc != OK:
@@ -201,7 +203,7 @@ class HipSampler:
     def set_state(self, pos, logp):
         pos = np.ascontiguousarray(pos, dtype=self.np_t)
         logp = np.ascontiguousarray(logp, dtype=self.np_t)
-        assert pos.size == self.W * self.D and logp.size == self.W
+        assert pos.size == self.K * self.W * self.D and logp.size == self.K * self.W
         self._check(lib().mcmcpp_hip_set_state(self.h, _ptr(pos), _ptr(logp)))
 
     def seek(self, ensemble_steps_done):
@@ -210,10 +212,11 @@ class HipSampler:
     def run(self, n_saved, interval=1, save_chain=True, want_accepted=True, out=None):
         """out: optional preallocated (n_saved, W, D) array receiving the stored steps (like a Chain block that
         already exists); by default a fresh array is allocated."""
+        lead = (self.K,) if self.K > 1 else ()  # several chains: chain[K][n_saved][W][D], acc[K][steps]
         if out is not None:
-            assert save_chain and out.shape == (n_saved, self.W, self.D) and out.dtype == self.np_t and out.flags.c_contiguous
-        chain = out if out is not None else (np.empty((n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None)
-        acc = np.zeros(n_saved * interval, dtype=np.uint32) if want_accepted else None
+            assert save_chain and out.shape == lead + (n_saved, self.W, self.D) and out.dtype == self.np_t and out.flags.c_contiguous
+        chain = out if out is not None else (np.empty(lead + (n_saved, self.W, self.D), dtype=self.np_t) if save_chain else None)
+        acc = np.zeros(lead + (n_saved * interval,), dtype=np.uint32) if want_accepted else None
         self._check(lib().mcmcpp_hip_run(self.h, n_saved, interval, _ptr(chain), _ptr(acc)))
         return chain, acc
 
@@ -232,9 +235,10 @@ class HipSampler:
         self._check(lib().mcmcpp_hip_run_wait(self.h))
 
     def get_state(self):
-        pos = np.empty((self.W, self.D), dtype=self.np_t)
-        logp = np.empty(self.W, dtype=self.np_t)
-        nacc = np.empty(self.W, dtype=np.uint32)
+        lead = (self.K,) if self.K > 1 else ()
+        pos = np.empty(lead + (self.W, self.D), dtype=self.np_t)
+        logp = np.empty(lead + (self.W,), dtype=self.np_t)
+        nacc = np.empty(lead + (self.W,), dtype=np.uint32)
         self._check(lib().mcmcpp_hip_get_state(self.h, _ptr(pos), _ptr(logp), _ptr(nacc)))
         return pos, logp, nacc
 

@@ -41,7 +41,7 @@ constexpr int kFullDrawWaves = MCMCPP_FULL_DRAW_WAVES;  // extra wavefronts of a
 
 // Hands the random stream and the step counters to the next full-step launch (one lane of the whole grid).
 template <class T>
-__device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const StepCtl& ctl, const RunInfo& run)
+__device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const StepCtl& ctl, const RunInfo& run, StepCtl* ctl_out)
 {
     StepCtl nx = ctl;
     nx.state = apply(a.half_jump, apply(a.half_jump, ctl.state));
@@ -52,7 +52,7 @@ __device__ __forceinline__ void hand_over_full(const HalfStepArgs<T>& a, const S
     nx.save_phase = saved ? 0u : ctl.save_phase + 1u;
     nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
     nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
-    *a.ctl_out = nx;  // (plain stores: written through, this and the partial counts below cost 0.2 us per launch)
+    *ctl_out = nx;  // (plain stores: written through, this and the partial counts below cost 0.2 us per launch)
 }
 
 // hot_bits of the full-step kernels: HotBits::pack(...) | pos_parity << 26
@@ -64,14 +64,14 @@ __host__ __device__ inline uint32_t full_step_bits(uint32_t half_bits, int pos_p
 template <class T>
 __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, const RunInfo* run_ptr,
                                                     bool block_barrier, DrawRec<T>* dn_red, int n, int sh_begin, int sh_count, int wpb, int which, int lane,
-                                                    int run_behind_ctl = -1)
+                                                    int run_behind_ctl = -1, int ctl_chain = 0)
 {
     const int black = kFullDrawWaves == 4 ? which >> 1 : which, half = kFullDrawWaves == 4 ? (which & 1) : 0;
     const int h0 = kFullDrawWaves == 4 ? (wpb + 1) / 2 : wpb;  // walkers of the first half
     DrawRec<T>* const dst = black ? dn_red + n : dn_red;
     // (the first of them also forwards this launch's slice of the last stored step: trickle_stored_step)
     draw_wave_body<T, 1>(a, tab, ctl_ptr, block_barrier, dst, dst, 1, sh_begin, sh_count, blockIdx.x * wpb + half * h0, half ? wpb - h0 : h0, lane, black != 0,
-                         which == 0 ? run_ptr : nullptr, which == 0 ? run_behind_ctl : -1);
+                         which == 0 ? run_ptr : nullptr, which == 0 ? run_behind_ctl : -1, ctl_chain);
 }
 
 // Both full-step kernels update walkers [sh_begin, sh_begin + sh_count) of EACH colour (the whole halves, or the slice
@@ -90,6 +90,15 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const HalfStepArgs<T>& a = rest;
     constexpr int WPP = 64 / LPW;  // walkers of each colour per wavefront
     const int h_n = hot_n;
+    // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
+    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const void* const draws_chain0 = hot_draws;
+    hot_draws += (size_t)chain * 4 * (size_t)h_n;
+    hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
+    hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
+    hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
+    // (the control record's address is not among the preloaded arguments: its chain offset is applied where it is used, chain_ctl)
+    hot_run = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(hot_run) + (size_t)chain * kCtlChainStride);
     const int h_dims = (int)(hot_bits & 0xFFFu);
     const bool vec_ok = ((hot_bits >> 21) & 1u) != 0;
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
@@ -122,8 +131,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const int wib = threadIdx.x >> 6;
     if (wib >= kWavesPerBlock)
     {
-        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, hot_run, Calc::block_scratch_elems(h_dims) != 0,
-                               dn_red, h_n, sh_begin, sh_count, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane);
+        full_step_draw_wave<T>(a, jump_tables_behind(draws_chain0, h_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in, hot_run, Calc::block_scratch_elems(h_dims) != 0,
+                               dn_red, h_n, sh_begin, sh_count, kWavesPerBlock * WPP, wib - kWavesPerBlock, lane, -1, chain);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + wib;
@@ -187,7 +196,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     // a microsecond each; issued one by one where first needed they delayed the calculator by about that much).
     StepCtl ctl;  // wave-uniform
     RunInfo run;
-    load_records_and_warm_args<T>(hot_ctl_in, hot_run, ctl, run);
+    const StepCtl* const ctl_mine = chain_ctl(hot_ctl_in, chain);
+    load_records_and_warm_args<T>(ctl_mine, hot_run, ctl, run);
 
     // ---- in its shadow: the calculator's tables, the hand-over to the next launch ----
     const bool has_block_scratch = Calc::block_scratch_elems(h_dims) != 0;
@@ -196,7 +206,7 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     ctx.block_scratch = has_block_scratch ? sh_block : nullptr;
     typename Calc::template Regs<EPL, LPW> cregs;
     Calc::template preload<EPL, LPW>(ctx, a.calc_params, cregs);
-    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run, const_cast<StepCtl*>(ctl_mine) + (h_flip ? -1 : 1));
     if (!wave_active) return;
 
     long long save_slot = -1;
@@ -308,7 +318,7 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     const unsigned acc_blk = (unsigned)__popcll(__ballot(acc_b && sub == 0));
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
     {
-        uint32_t* p = a.partials + (size_t)ctl.partial_slot * 2 * (size_t)a.partial_waves;
+        uint32_t* p = a.partials + ((size_t)chain * (size_t)a.partial_slots + (size_t)ctl.partial_slot) * 2 * (size_t)a.partial_waves;
         p[wave] = acc_red;
         p[(size_t)a.partial_waves + wave] = acc_blk;
     }
@@ -350,6 +360,13 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     MCMCPP_STAMP_BLOCK(0);
     const int h_n = hot_n;
     const int h_dims = (int)(hot_bits & 0xFFFu);
+    // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
+    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const void* const draws_chain0 = hot_draws;
+    hot_draws += (size_t)chain * 4 * (size_t)h_n;
+    hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
+    hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
+    hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
     const bool h_flip = ((hot_bits >> 26) & 1u) != 0;
@@ -369,8 +386,8 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
         // (the run record's address is derived from the control record's, where it is needed: run_record_behind)
-        full_step_draw_wave<T>(a, jump_tables_behind(hot_draws, h_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, nullptr, false, dn_red, h_n, sh_begin, sh_count,
-                               kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0);
+        full_step_draw_wave<T>(a, jump_tables_behind(draws_chain0, h_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in, nullptr, false, dn_red, h_n, sh_begin,
+                               sh_count, kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0, chain);
         return;
     }
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -435,8 +452,9 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
     StepCtl ctl;
     RunInfo run;
-    load_records_and_warm_args<T>(hot_ctl_in, run_record_behind(hot_ctl_in, h_flip ? 1 : 0), ctl, run);
-    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run);
+    const StepCtl* const ctl_mine = chain_ctl(hot_ctl_in, chain);  // (the chain's own records: derived here, where a wait is free)
+    load_records_and_warm_args<T>(ctl_mine, run_record_behind(ctl_mine, h_flip ? 1 : 0), ctl, run);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run, const_cast<StepCtl*>(ctl_mine) + (h_flip ? -1 : 1));
     long long save_slot = -1;
     if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;
 
@@ -535,7 +553,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
 #endif
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
     {
-        uint32_t* p = a.partials + (size_t)ctl.partial_slot * 2 * (size_t)a.partial_waves;
+        uint32_t* p = a.partials + ((size_t)chain * (size_t)a.partial_slots + (size_t)ctl.partial_slot) * 2 * (size_t)a.partial_waves;
         p[wave] = acc_red;
         p[(size_t)a.partial_waves + wave] = acc_blk;
     }

@@ -39,8 +39,10 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr), a.pos_parity);
-    hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
+    const int chains = a.chains > 1 ? a.chains : 1;
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr), a.pos_parity) |
+                          ((uint32_t)(chains - 1) << 28);
+    hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
                        st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 
@@ -48,10 +50,12 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
-    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity);
+    const int chains = a.chains > 1 ? a.chains : 1;
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity) |
+                          ((uint32_t)(chains - 1) << 28);
     // (logp_alt == logp + W, n_accept == logp + 2 W and the run record kRunBehindCtlBytes behind the control records: the
     //  kernel derives them and takes the padded matrix and the shard bounds as preloaded arguments instead)
-    hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+    hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
                        a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 

@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D43000Cu;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D43000Du;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -42,7 +42,7 @@ struct LaunchTable
 void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, const U128* red_base, hipStream_t stream);
 void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_base, hipStream_t stream);
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
-                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream);
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains = 1);
 
 // one definition per (element type, calculator), each in its own translation unit
 const LaunchTable<double>* launch_table_f64_iso();

@@ -189,9 +189,9 @@ void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_
     hipLaunchKernelGGL(fill_draws_kernel<float>, dim3(grid), dim3(256), 0, stream, a, base, red_base ? *red_base : base, red_base ? 1 : 0);
 }
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
-                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream)
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains)
 {
-    hipLaunchKernelGGL(accepted_reduce_kernel, dim3((unsigned)count), dim3(256), 0, stream, partials, partial_slots,
+    hipLaunchKernelGGL(accepted_reduce_kernel, dim3((unsigned)count, (unsigned)(chains > 1 ? chains : 1)), dim3(256), 0, stream, partials, partial_slots,
                        partial_waves, count, ctl_after, run);
 }
 }  // namespace mcmcpp
@@ -333,6 +333,15 @@ public:
             }
         }
 
+        // Independent ensembles stepped by the same launches (BASELINE config 4 on one GPU): chain k is seeded with
+        // seed + k on the same stream, so all chains share the jump tables; see ChainGeometry for the layout.
+        K = c.num_chains > 1 ? c.num_chains : 1;
+        if (K > 1)
+        {
+            if (K > kMaxChains) return fail(MCMCPP_HIP_E_ARG, "num_chains %d exceeds %d", K, kMaxChains);
+            if (!full_fn) return fail(MCMCPP_HIP_E_UNSUPPORTED, "num_chains > 1 needs ensembles of at most %ld walkers (one launch per ensemble step)", knobs.full_step_max_walkers);
+            if (!whole || c.comm_world >= 1 || c.device_positions) return fail(MCMCPP_HIP_E_ARG, "num_chains > 1: whole ensembles on one device only (no shards, communicator or caller-owned positions)");
+        }
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
         {
             stream = (hipStream_t)c.hip_stream;  // may be the null (legacy default) stream
@@ -356,10 +365,10 @@ public:
             // upper bound of everything carved below (each piece rounded up to 256 bytes)
             const size_t graph_len = (size_t)(c.graph_steps == 0 ? default_graph_steps() : (c.graph_steps > 0 ? c.graph_steps : 1));
             const size_t waves_bound = (size_t)n + 64;  // no kernel uses more wavefronts per colour than walkers
-            size_t need = 2 * sizeof(T) * (size_t)W * D                 // pos, pos_alt
-                          + sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W + tables_total_bytes(n, true)
+            size_t need = (size_t)K * 2 * sizeof(T) * (size_t)W * D    // pos, pos_alt
+                          + (size_t)K * logp_chain_stride_bytes<T>(n) + (size_t)K * kCtlChainStride + tables_total_bytes(n, true, K)
                           + sizeof(T) * ((size_t)(c.calc_params_len > 0 ? c.calc_params_len : 0) + 32 * 32)
-                          + sizeof(uint32_t) * graph_len * 2 * waves_bound + 64 * 1024;
+                          + (size_t)K * sizeof(uint32_t) * graph_len * 2 * waves_bound + 64 * 1024;
             HIP_TRY(hipMalloc(&arena, need));
             arena_bytes = need;
             arena_used = 0;
@@ -372,21 +381,22 @@ public:
         }
         else
         {
-            if (int rc = carve(&d_pos, sizeof(T) * (size_t)W * D)) return rc;
+            if (int rc = carve(&d_pos, sizeof(T) * (size_t)W * D * K)) return rc;
             own_pos = true;
         }
         // log-posteriors [2][W] (the second half is the full-step kernels' other buffer) and, right behind them, the
         // accepted counters [W]: one piece, so that kernels short of preloaded arguments can derive both addresses
-        if (int rc = carve(&d_logp, sizeof(T) * (size_t)W * 2 + sizeof(uint32_t) * (size_t)W)) return rc;
+        static_assert(sizeof(StepCtl) == 64 && sizeof(RunInfo) == 64 && kRunBehindCtlBytes + (int)sizeof(RunInfo) <= kCtlChainStride, "ChainGeometry");
+        if (int rc = carve(&d_logp, logp_chain_stride_bytes<T>(n) * (size_t)K)) return rc;
         d_nacc = reinterpret_cast<uint32_t*>(d_logp + 2 * (size_t)W);
         if (full_fn)
-            if (int rc = carve(&d_pos_alt, sizeof(T) * (size_t)W * D)) return rc;
+            if (int rc = carve(&d_pos_alt, sizeof(T) * (size_t)W * D * K)) return rc;
         {
             // the two control records and, kRunBehindCtlBytes behind the first, the run record: one piece (a kernel short
             // of preloaded arguments derives the run record's address)
             static_assert(2 * sizeof(StepCtl) <= (size_t)kRunBehindCtlBytes, "the run record follows the control records");
             char* piece = nullptr;
-            if (int rc = carve(&piece, (size_t)kRunBehindCtlBytes + sizeof(RunInfo))) return rc;
+            if (int rc = carve(&piece, (size_t)kCtlChainStride * (size_t)K)) return rc;
             d_ctl = reinterpret_cast<StepCtl*>(piece);
             d_run = reinterpret_cast<RunInfo*>(piece + kRunBehindCtlBytes);
         }
@@ -397,22 +407,23 @@ public:
         have_task_table = (size_t)3 * n * sizeof(Affine128) <= ((size_t)knobs.task_table_mb << 20);
         {
             char* piece = nullptr;
-            if (int rc = carve(&piece, tables_total_bytes(n, have_task_table))) return rc;
+            if (int rc = carve(&piece, tables_total_bytes(n, have_task_table, K))) return rc;
             d_draws = reinterpret_cast<DrawRec<T>*>(piece);
-            d_task_jump = have_task_table ? reinterpret_cast<Affine128*>(piece + tables_offset_task(n)) : nullptr;
-            d_jump_hi = reinterpret_cast<Affine128*>(piece + tables_offset_hi(n, have_task_table));
-            d_jump_lo = reinterpret_cast<Affine128*>(piece + tables_offset_lo(n, have_task_table));
+            d_task_jump = have_task_table ? reinterpret_cast<Affine128*>(piece + tables_offset_task(n, K)) : nullptr;
+            d_jump_hi = reinterpret_cast<Affine128*>(piece + tables_offset_hi(n, have_task_table, K));
+            d_jump_lo = reinterpret_cast<Affine128*>(piece + tables_offset_lo(n, have_task_table, K));
         }
-        HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2));
+        HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2 * K));
 #ifdef MCMCPP_STAMPS
         HIP_TRY(hipMalloc(&d_stamps, kStampWords * sizeof(unsigned long long)));  // [8 stamps][2 alternating launches][start, end of 4096 workgroups | end of their draw wavefronts]
         HIP_TRY(hipMemset(d_stamps, 0, kStampWords * sizeof(unsigned long long)));
 #endif
-        HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
+        HIP_TRY(hipMemset(d_logp, 0, logp_chain_stride_bytes<T>(n) * (size_t)K));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
-        HIP_TRY(hipMemset(d_run, 0, sizeof(RunInfo)));
-        HIP_TRY(hipMemset(d_ctl, 0, sizeof(StepCtl) * 2));
-        HIP_TRY(hipHostMalloc(&h_pinned, 512, hipHostMallocDefault));
+        HIP_TRY(hipMemset(d_ctl, 0, (size_t)kCtlChainStride * (size_t)K));
+        // pinned scratch of the host: [0, 512) as before (control record at 128, four run records from 256 on);
+        // per-chain control records from 1024, per-chain run records from 1024 + 64 * kMaxChains on
+        HIP_TRY(hipHostMalloc(&h_pinned, 1024 + 128 * kMaxChains, hipHostMallocDefault));
 
         // calculator parameters (the dense Gaussian's matrix goes over transposed: see DenseGaussianFn)
         if (c.calc_params_len > 0)
@@ -439,6 +450,11 @@ public:
 
         // pcg64 stream (MultiSampler.h:54) and its jump tables
         pcg_seed(c.seed, c.stream, &state0, &inc);
+        for (int k = 0; k < K; ++k)
+        {
+            U128 inc_k;
+            pcg_seed(c.seed + (uint64_t)k, c.stream, &state0_of[k], &inc_k);  // (same stream: the same increment)
+        }
         {
             std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256);
             const Affine128 step3 = pcg_jump(inc, 3);
@@ -468,8 +484,8 @@ public:
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
         if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;
-        if (int rc = carve(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves)) return rc;
-        HIP_TRY(hipMemset(d_partials, 0, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves));
+        if (int rc = carve(&d_partials, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves * K)) return rc;
+        HIP_TRY(hipMemset(d_partials, 0, sizeof(uint32_t) * (size_t)partial_slots * 2 * (size_t)partial_waves * K));
         chain_subchunk_bytes = (size_t)knobs.chain_subchunk_mb << 20;
         return MCMCPP_HIP_OK;
     }
@@ -497,9 +513,12 @@ public:
     {
         if (!pos || !logp) return fail(MCMCPP_HIP_E_ARG, "set_state: null pointer");
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipMemcpyAsync(d_pos, pos, sizeof(T) * (size_t)W * D, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(d_logp, logp, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
+        HIP_TRY(hipMemcpyAsync(d_pos, pos, sizeof(T) * (size_t)W * D * K, hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < K; ++k)
+        {
+            HIP_TRY(hipMemcpyAsync(logp_of(k), (const T*)logp + (size_t)k * W, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemsetAsync(nacc_of(k), 0, sizeof(uint32_t) * (size_t)W, stream));
+        }
         HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(Diag), stream));
         half_steps = 0;
         steps_since_reset = 0;
@@ -573,7 +592,7 @@ public:
         const bool trickle = full_fn && chain_out && step_bytes % 16 == 0 && knobs.trickle != 0;
         // chain_out in pinned host memory (mcmcpp_hip_host_alloc: the facade's Chain blocks): the launches forward stored
         // steps straight into their final place -- no pinned twin of the device ring, no host copy
-        void* direct_stage = (trickle && knobs.pinned_direct != 0) ? device_view_of_pinned(chain_out, step_bytes * (size_t)n_saved) : nullptr;
+        void* direct_stage = (trickle && knobs.pinned_direct != 0) ? device_view_of_pinned(chain_out, step_bytes * (size_t)n_saved * K) : nullptr;
         int64_t ring = 0, chunk_steps = 0;
         if (trickle)
         {
@@ -585,10 +604,11 @@ public:
             if (per_chunk < 1) per_chunk = 1;
             chunk_steps = per_chunk * interval;
         }
-        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved : 0,
-                                    trickle ? step_bytes * (size_t)ring : 0, direct_stage == nullptr);
+        if (K > 1 && chain_out && !trickle) return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: several chains store steps only through the forwarding path (rows of whole 16-byte pieces)");
+        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total * K : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved : 0,
+                                    trickle ? step_bytes * (size_t)ring * K : 0, direct_stage == nullptr);
         if (rc) return rc;
-        if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
+        if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total * K, stream));
         run_touched_device = true;  // from here on an error leaves the device ahead of the host's bookkeeping
         rc = write_ctl(0);  // step_in_run = 0, stream position from the host-side half-step count
         if (rc) return rc;
@@ -596,7 +616,8 @@ public:
         run_info_idle = false;
         if (full_fn)
         {
-            hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, d_nacc, W, kRowMovedBit);
+            for (int k = 0; k < K; ++k)
+                hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, nacc_of(k), W, kRowMovedBit);
             HIP_TRY(hipGetLastError());
         }
         enq_step = half_steps >> 1;
@@ -621,17 +642,22 @@ public:
             const int buf = (int)(c & 1);
             const int64_t first = c * sub_saved;
             const int64_t now = (n_saved - first < sub_saved) ? n_saved - first : sub_saved;
-            RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256 + 64 * (c % 4));
-            static_assert(sizeof(RunInfo) <= 64, "the pinned upload slots are 64 bytes apart");
-            ri->chain = chain_out ? d_chain[buf] : nullptr;
-            ri->accepted_per_step = accepted_per_step ? d_acc : nullptr;
-            ri->interval = interval;
-            ri->chain_slot_base = -first;
-            ri->stage = nullptr;
-            ri->slot_mask = -1;
-            ri->slice_bytes = 0;
-            ri->step_bytes = (int64_t)step_bytes;
-            HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+            for (int k = 0; k < K; ++k)
+            {
+                // (several chains: nothing is stored on this path, one record each, uploaded once)
+                RunInfo* ri = K > 1 ? reinterpret_cast<RunInfo*>((char*)h_pinned + 1024 + 64 * kMaxChains + 64 * k)
+                                    : reinterpret_cast<RunInfo*>((char*)h_pinned + 256 + 64 * (c % 4));
+                static_assert(sizeof(RunInfo) <= 64, "the pinned upload slots are 64 bytes apart");
+                ri->chain = chain_out ? d_chain[buf] : nullptr;
+                ri->accepted_per_step = accepted_per_step ? d_acc + (size_t)k * (size_t)total : nullptr;
+                ri->interval = interval;
+                ri->chain_slot_base = -first;
+                ri->stage = nullptr;
+                ri->slot_mask = -1;
+                ri->slice_bytes = 0;
+                ri->step_bytes = (int64_t)step_bytes;
+                HIP_TRY(hipMemcpyAsync(run_of(k), ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+            }
             // the events of slot c%4 were last used by sub-chunk c-4, which has long been waited for
             HIP_TRY(hipEventRecord(ev_t0[c & 3], stream));
             rc = enqueue_steps(now * interval);
@@ -684,9 +710,12 @@ public:
             {
                 // an odd number of full steps leaves the ensemble in the second buffer: bring it (and the control
                 // record) home, so that everything outside run() only ever knows the first
-                HIP_TRY(hipMemcpyAsync(d_pos, d_pos_alt, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToDevice, stream));
-                HIP_TRY(hipMemcpyAsync(d_logp, d_logp + W, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
-                HIP_TRY(hipMemcpyAsync(d_ctl, d_ctl + 1, sizeof(StepCtl), hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_pos, d_pos_alt, sizeof(T) * (size_t)W * D * K, hipMemcpyDeviceToDevice, stream));
+                for (int k = 0; k < K; ++k)
+                {
+                    HIP_TRY(hipMemcpyAsync(logp_of(k), logp_of(k) + W, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                    HIP_TRY(hipMemcpyAsync(ctl_of(k), ctl_of(k) + 1, sizeof(StepCtl), hipMemcpyDeviceToDevice, stream));
+                }
             }
             HIP_TRY(hipStreamSynchronize(stream));
             for (int64_t c = (n_sub > 3 ? n_sub - 3 : 0); c < n_sub; ++c)
@@ -696,7 +725,7 @@ public:
                 launch_ms += ms;
             }
             last_ms = launch_ms;
-            last_launches = full_fn ? total : 2 * total;
+            last_launches = full_fn ? total : 2 * total;  // (a launch steps all chains)
             half_steps += 2 * (uint64_t)total;
             steps_since_reset += (uint64_t)total;
             // the last launch left the records of the next ensemble step behind (full-step launches: with partner2)
@@ -704,7 +733,7 @@ public:
             records_step = half_steps >> 1;
             records_partner2 = full_fn != nullptr;
             if (accepted_per_step)
-                HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(accepted_per_step, d_acc, sizeof(uint32_t) * (size_t)total * K, hipMemcpyDeviceToHost));
         }
         const auto tp3 = std::chrono::steady_clock::now();
         host_enqueue_ms = std::chrono::duration<double, std::milli>(tp2 - tp1).count();
@@ -864,7 +893,7 @@ public:
                     slice(args_red, r);
                     enqueue_step(parity, pos_parity);
                 }
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
                 HIP_TRY(hipGetLastError());
                 cur_pos = pos_parity ? d_pos : d_pos_alt;
                 T* cur_logp = pos_parity ? d_logp : d_logp + W;
@@ -893,7 +922,7 @@ public:
                     slice(args_blk, r);
                     half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
                 }
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
                 HIP_TRY(hipGetLastError());
                 rc = exchange_rows(d_pos, nullptr, 1, 1);
                 if (rc) return rc;
@@ -967,16 +996,22 @@ public:
     {
         const int64_t total = n_saved * (int64_t)interval;
         const bool direct = direct_stage != nullptr;  // the launches forward into chain_out itself (pinned memory)
-        RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256);
-        ri->chain = d_ring;
-        ri->accepted_per_step = want_accepted ? d_acc : nullptr;
-        ri->interval = interval;
-        ri->chain_slot_base = 0;
-        ri->stage = direct ? (void*)direct_stage : h_ring;
-        ri->slot_mask = ring - 1;
-        ri->slice_bytes = (int64_t)(((step_bytes + (size_t)interval - 1) / (size_t)interval + 15) / 16 * 16) | (direct ? 1 : 0);
-        ri->step_bytes = (int64_t)step_bytes;
-        HIP_TRY(hipMemcpyAsync(d_run, ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+        // chain k: its own ring of stored steps on the device (and, unless the launches forward into chain_out itself,
+        // its own twin in pinned memory); in the caller's memory chain k is the k-th run of n_saved steps
+        const size_t ring_bytes = step_bytes * (size_t)ring, out_bytes = step_bytes * (size_t)n_saved;
+        for (int k = 0; k < K; ++k)
+        {
+            RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 1024 + 64 * kMaxChains + 64 * k);
+            ri->chain = (char*)d_ring + ring_bytes * (size_t)k;
+            ri->accepted_per_step = want_accepted ? d_acc + (size_t)k * (size_t)total : nullptr;
+            ri->interval = interval;
+            ri->chain_slot_base = 0;
+            ri->stage = direct ? (void*)(direct_stage + out_bytes * (size_t)k) : (void*)((char*)h_ring + ring_bytes * (size_t)k);
+            ri->slot_mask = ring - 1;
+            ri->slice_bytes = (int64_t)(((step_bytes + (size_t)interval - 1) / (size_t)interval + 15) / 16 * 16) | (direct ? 1 : 0);
+            ri->step_bytes = (int64_t)step_bytes;
+            HIP_TRY(hipMemcpyAsync(run_of(k), ri, sizeof(RunInfo), hipMemcpyHostToDevice, stream));
+        }
 
         int64_t enq = 0, copied = 0;       // ensemble steps enqueued; stored steps handed to the caller
         int64_t chunk_end[4] = {0, 0, 0, 0};
@@ -994,14 +1029,15 @@ public:
             }
             else
                 for (; copied < complete; ++copied)
-                {
-                    char* dst = chain_out + step_bytes * (size_t)copied;
-                    const char* src = (char*)h_ring + step_bytes * (size_t)(copied & (ring - 1));
-                    if (enq == total)
-                        parallel_memcpy(dst, src, step_bytes);  // nothing left to overlap with: be quick
-                    else
-                        std::memcpy(dst, src, step_bytes);
-                }
+                    for (int k = 0; k < K; ++k)
+                    {
+                        char* dst = chain_out + out_bytes * (size_t)k + step_bytes * (size_t)copied;
+                        const char* src = (char*)h_ring + ring_bytes * (size_t)k + step_bytes * (size_t)(copied & (ring - 1));
+                        if (enq == total)
+                            parallel_memcpy(dst, src, step_bytes);  // nothing left to overlap with: be quick
+                        else
+                            std::memcpy(dst, src, step_bytes);
+                    }
             publish_stored(copied);
             ++oldest;
             return MCMCPP_HIP_OK;
@@ -1028,9 +1064,10 @@ public:
         }
         // What the launches do not forward: the run's last stored step.  Its download is queued now, behind the last
         // launch, so that it runs while the host still copies out the steps before it.
+        for (int k = 0; k < K; ++k)
         {
-            const size_t off = step_bytes * (size_t)((n_saved - 1) & (ring - 1));
-            char* dst = direct ? chain_out + step_bytes * (size_t)(n_saved - 1) : (char*)h_ring + off;
+            const size_t off = ring_bytes * (size_t)k + step_bytes * (size_t)((n_saved - 1) & (ring - 1));
+            char* dst = direct ? chain_out + out_bytes * (size_t)k + step_bytes * (size_t)(n_saved - 1) : (char*)h_ring + off;
             HIP_TRY(hipMemcpyAsync(dst, (char*)d_ring + off, step_bytes, hipMemcpyDeviceToHost, stream));
         }
         while (next_chunk > oldest)
@@ -1043,10 +1080,11 @@ public:
             copied = n_saved;
         else
             for (; copied < n_saved; ++copied)  // (exactly one: every earlier one has been forwarded and copied above)
-            {
-                const size_t off = step_bytes * (size_t)(copied & (ring - 1));
-                parallel_memcpy(chain_out + step_bytes * (size_t)copied, (char*)h_ring + off, step_bytes);
-            }
+                for (int k = 0; k < K; ++k)
+                {
+                    const size_t off = ring_bytes * (size_t)k + step_bytes * (size_t)(copied & (ring - 1));
+                    parallel_memcpy(chain_out + out_bytes * (size_t)k + step_bytes * (size_t)copied, (char*)h_ring + off, step_bytes);
+                }
         publish_stored(copied);
         return MCMCPP_HIP_OK;
     }
@@ -1075,13 +1113,14 @@ public:
         if (!have_state) return fail(MCMCPP_HIP_E_STATE, "get_state: no walker state (set_state has not been called, or a run failed half way)");
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamSynchronize(stream));
-        if (pos) HIP_TRY(hipMemcpy(pos, d_pos, sizeof(T) * (size_t)W * D, hipMemcpyDeviceToHost));
-        if (logp) HIP_TRY(hipMemcpy(logp, d_logp, sizeof(T) * (size_t)W, hipMemcpyDeviceToHost));
-        if (n_accept)
+        if (pos) HIP_TRY(hipMemcpy(pos, d_pos, sizeof(T) * (size_t)W * D * K, hipMemcpyDeviceToHost));
+        for (int k = 0; k < K; ++k)
         {
-            HIP_TRY(hipMemcpy(n_accept, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
-            for (int w = 0; w < W; ++w) n_accept[w] &= ~kRowMovedBit;  // (the top bit is the full-step kernels' bookkeeping)
+            if (logp) HIP_TRY(hipMemcpy((T*)logp + (size_t)k * W, logp_of(k), sizeof(T) * (size_t)W, hipMemcpyDeviceToHost));
+            if (n_accept) HIP_TRY(hipMemcpy(n_accept + (size_t)k * W, nacc_of(k), sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
         }
+        if (n_accept)
+            for (size_t w = 0; w < (size_t)W * K; ++w) n_accept[w] &= ~kRowMovedBit;  // (the top bit is the full-step kernels' bookkeeping)
         return MCMCPP_HIP_OK;
     }
 
@@ -1098,7 +1137,7 @@ public:
     int reset_counters() override
     {
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
+        for (int k = 0; k < K; ++k) HIP_TRY(hipMemsetAsync(nacc_of(k), 0, sizeof(uint32_t) * (size_t)W, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         steps_since_reset = 0;
         return MCMCPP_HIP_OK;
@@ -1111,10 +1150,13 @@ public:
         if (accepted)
         {
             std::vector<uint32_t> a((size_t)W);
-            HIP_TRY(hipMemcpy(a.data(), d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
             uint64_t s = 0;
-            for (int c = 0; c < 2; ++c)
-                for (int i = 0; i < shard_count; ++i) s += a[(size_t)c * n + shard_begin + i] & ~kRowMovedBit;
+            for (int k = 0; k < K; ++k)
+            {
+                HIP_TRY(hipMemcpy(a.data(), nacc_of(k), sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToHost));
+                for (int c = 0; c < 2; ++c)
+                    for (int i = 0; i < shard_count; ++i) s += a[(size_t)c * n + shard_begin + i] & ~kRowMovedBit;
+            }
             *accepted = s;
         }
         if (steps) *steps = steps_since_reset;
@@ -1164,6 +1206,7 @@ public:
 
     int half_step_async(int32_t color, int64_t save_slot) override
     {
+        if (K > 1) return fail(MCMCPP_HIP_E_UNSUPPORTED, "half_step_async: not with several chains per handle");
         if (!have_state) return fail(MCMCPP_HIP_E_STATE, "half_step_async: set_state has not been called");
         if (color != (int)(half_steps & 1)) return fail(MCMCPP_HIP_E_ARG, "half_step_async: colour %d out of order", color);
         if (save_slot >= 0 && (!bound_chain || save_slot >= bound_slots))
@@ -1248,6 +1291,12 @@ private:
         return MCMCPP_HIP_OK;
     }
 
+    // chain k's arrays (ChainGeometry; k = 0: the arrays themselves)
+    T* logp_of(int k) const { return reinterpret_cast<T*>(reinterpret_cast<char*>(d_logp) + logp_chain_stride_bytes<T>(n) * (size_t)k); }
+    uint32_t* nacc_of(int k) const { return reinterpret_cast<uint32_t*>(logp_of(k) + 2 * (size_t)W); }
+    StepCtl* ctl_of(int k) const { return reinterpret_cast<StepCtl*>(reinterpret_cast<char*>(d_ctl) + (size_t)kCtlChainStride * (size_t)k); }
+    RunInfo* run_of(int k) const { return reinterpret_cast<RunInfo*>(reinterpret_cast<char*>(d_run) + (size_t)kCtlChainStride * (size_t)k); }
+
     unsigned grid_blocks() const { return grid_blocks_for(shard_count); }
     unsigned grid_blocks_for(int count) const
     {
@@ -1313,6 +1362,7 @@ private:
         a.logp_alt = d_logp + W;
         a.pos_parity = 0;
         a.calc_params_padded = d_params_padded;
+        a.chains = K;
         // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
         a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && knobs.no_draw_wave == 0) ? 1 : 0;
         return a;
@@ -1321,25 +1371,34 @@ private:
     // device StepCtl[0] <- {stream position of half-step `half_steps`, counters}; half_steps must be even
     int write_ctl(uint64_t step_in_run)
     {
-        StepCtl* c = (StepCtl*)((char*)h_pinned + 128);
         const Affine128 j = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps);
-        c->state = apply(j, state0);
-        const U128 state1 = apply(half_jump, c->state);
-        c->state2 = apply(half_jump, state1);
-        c->half_step = half_steps;
-        c->step_in_run = step_in_run;
-        c->chain_slot = 0;
-        c->save_phase = 0;
-        c->partial_slot = 0;
-        HIP_TRY(hipMemcpyAsync(d_ctl + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
         // the draw records of the next red and the next black half-step (afterwards the launches keep them going):
         // unless the launches of the previous call left exactly these behind
-        if (!(records_valid && records_step == (half_steps >> 1) && (!full_fn || records_partner2)))
+        const bool refill = !(records_valid && records_step == (half_steps >> 1) && (!full_fn || records_partner2));
+        for (int k = 0; k < K; ++k)
         {
-            const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
-            launch_fill_draws(make_args(0, parity), c->state, nullptr, stream);
-            launch_fill_draws(make_args(1, parity), state1, full_fn ? &c->state : nullptr, stream);
-            HIP_TRY(hipGetLastError());
+            StepCtl* c = K > 1 ? (StepCtl*)((char*)h_pinned + 1024 + 64 * k) : (StepCtl*)((char*)h_pinned + 128);
+            c->state = apply(j, state0_of[k]);
+            const U128 state1 = apply(half_jump, c->state);
+            c->state2 = apply(half_jump, state1);
+            c->half_step = half_steps;
+            c->step_in_run = step_in_run;
+            c->chain_slot = 0;
+            c->save_phase = 0;
+            c->partial_slot = 0;
+            HIP_TRY(hipMemcpyAsync(ctl_of(k) + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
+            if (refill)
+            {
+                const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
+                HalfStepArgs<T> fr = make_args(0, parity), fb = make_args(1, parity);
+                fr.draws = fb.draws = d_draws + (size_t)k * 4 * (size_t)n;  // (the chain's own records; the tables are shared)
+                launch_fill_draws(fr, c->state, nullptr, stream);
+                launch_fill_draws(fb, state1, full_fn ? &c->state : nullptr, stream);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (refill)
+        {
             records_valid = true;
             records_step = half_steps >> 1;
             records_partner2 = full_fn != nullptr;
@@ -1382,7 +1441,7 @@ private:
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
             for (int s = 0; s < steps; ++s) enqueue_step((start_parity + s) & 1, (pos_parity + s) & 1);
-            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream);
+            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream, K);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -1435,7 +1494,7 @@ private:
             for (; left > 0; --left)
             {
                 enqueue_step((int)(enq_step & 1), (int)(run_step & 1));
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream);
+                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
                 enq_step += 1;
                 run_step += 1;
             }
@@ -1590,6 +1649,8 @@ private:
     uint64_t records_step = 0;
     void* h_pinned = nullptr;
     U128 state0, inc;
+    U128 state0_of[kMaxChains];  // per chain (seed + k)
+    int K = 1;                   // independent ensembles stepped by one launch
     Affine128 half_jump;
     HalfStepArgs<T> args_red, args_blk;
     std::vector<hipGraphExec_t> graph_cache;  // [steps] -> instantiated graph
@@ -1642,6 +1703,8 @@ int check_config(const mcmcpp_hip_config* c, std::string& err)
     if (c->shard_begin < 0 || c->shard_count < 0) BAD("negative shard bounds");
     if (c->mover != MCMCPP_HIP_MOVER_STRETCH && c->mover != MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION) BAD("unknown mover %u", c->mover);
     if (c->comm_world < 0) BAD("comm_world must not be negative");
+    if (c->num_chains < 0) BAD("num_chains must not be negative");
+    if (c->num_chains > 1 && c->mover != MCMCPP_HIP_MOVER_STRETCH) BAD("several chains per handle: StretchMove only");
     if (c->mover == MCMCPP_HIP_MOVER_DIFFERENTIAL_EVOLUTION && (c->shard_count != 0 || c->device_positions || c->comm_world >= 1))
         BAD("the differential-evolution mover runs one whole ensemble per handle (no shards, no caller-owned position buffer)");
     if (c->gw_alpha_num < 0 || c->gw_alpha_den < 0 || ((c->gw_alpha_num == 0) != (c->gw_alpha_den == 0)))

@@ -94,25 +94,40 @@ struct JumpTables
     const Affine128* lo;
 };
 __host__ __device__ inline size_t round_up_256(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-__host__ __device__ inline size_t tables_offset_task(int n) { return round_up_256((size_t)4 * (size_t)n * 32); }
-__host__ __device__ inline size_t tables_offset_hi(int n, bool direct)
+// (`chains` independent ensembles stepped by one launch share the tables: same stream increment, see ChainGeometry)
+__host__ __device__ inline size_t tables_offset_task(int n, int chains = 1) { return round_up_256((size_t)4 * (size_t)n * 32 * (size_t)chains); }
+__host__ __device__ inline size_t tables_offset_hi(int n, bool direct, int chains = 1)
 {
-    return tables_offset_task(n) + (direct ? round_up_256((size_t)3 * (size_t)n * sizeof(Affine128)) : 0);
+    return tables_offset_task(n, chains) + (direct ? round_up_256((size_t)3 * (size_t)n * sizeof(Affine128)) : 0);
 }
-__host__ __device__ inline size_t tables_offset_lo(int n, bool direct)
+__host__ __device__ inline size_t tables_offset_lo(int n, bool direct, int chains = 1)
 {
-    return tables_offset_hi(n, direct) + round_up_256((size_t)((n + 255) / 256) * sizeof(Affine128));
+    return tables_offset_hi(n, direct, chains) + round_up_256((size_t)((n + 255) / 256) * sizeof(Affine128));
 }
-__host__ __device__ inline size_t tables_total_bytes(int n, bool direct) { return tables_offset_lo(n, direct) + 256 * sizeof(Affine128); }
-__device__ __forceinline__ JumpTables jump_tables_behind(const void* draws_base, int n, bool direct)
+__host__ __device__ inline size_t tables_total_bytes(int n, bool direct, int chains = 1) { return tables_offset_lo(n, direct, chains) + 256 * sizeof(Affine128); }
+__device__ __forceinline__ JumpTables jump_tables_behind(const void* draws_base, int n, bool direct, int chains = 1)
 {
     const char* b = static_cast<const char*>(draws_base);
     JumpTables t;
-    t.task = direct ? reinterpret_cast<const Affine128*>(b + tables_offset_task(n)) : nullptr;
-    t.hi = reinterpret_cast<const Affine128*>(b + tables_offset_hi(n, direct));
-    t.lo = reinterpret_cast<const Affine128*>(b + tables_offset_lo(n, direct));
+    t.task = direct ? reinterpret_cast<const Affine128*>(b + tables_offset_task(n, chains)) : nullptr;
+    t.hi = reinterpret_cast<const Affine128*>(b + tables_offset_hi(n, direct, chains));
+    t.lo = reinterpret_cast<const Affine128*>(b + tables_offset_lo(n, direct, chains));
     return t;
 }
+
+// Several independent ensembles ("chains": BASELINE config 4 on one GPU) stepped by ONE launch: workgroup row
+// blockIdx.y is chain blockIdx.y.  Every per-chain array is the single-chain array repeated with a fixed stride that
+// follows from n and D alone, so the kernels need no further arguments (the chain count travels in the hot bits):
+//   positions (both buffers)   [chains][2n][D]
+//   log-posteriors + counters  [chains]{[2][2n] T, [2n] u32}
+//   control + run records      [chains]{StepCtl[2], pad to kRunBehindCtlBytes, RunInfo, pad to kCtlChainStride}
+//   draw records               [chains][2][2][n], then the shared jump tables
+//   partial accepted counts    [chains][partial_slots][2][partial_waves]
+// The chains differ in their seed (seed + chain: same stream increment, hence the same jump tables).
+constexpr int kCtlChainStride = 512;  // (chain_ctl spells the number out)
+constexpr int kMaxChains = 16;  // (four hot bits)
+template <class T>
+__host__ __device__ inline size_t logp_chain_stride_bytes(int n) { return (size_t)4 * (size_t)n * sizeof(T) + (size_t)2 * (size_t)n * sizeof(uint32_t); }
 
 // The launch description.  It travels by value in the kernarg segment (behind 64 bytes of preloaded hot arguments)
 // and is read with scalar loads where a field is first used; after a launch boundary every 64-byte line of it is a
@@ -166,6 +181,7 @@ struct alignas(64) HalfStepArgs
     int draw_parity;            // ensemble step & 1: which record buffer this launch reads
     int draw_wave;              // 1: the workgroup carries extra wavefronts that compute the next draws
     int pos_parity;             // full-step kernels: 0: read pos/logp, write pos_alt/logp_alt; 1: the reverse
+    int chains;                 // full-step kernels: independent ensembles stepped by this launch (grid.y), 1..kMaxChains
 };
 
 // This lane's EPL elements of a walker row; cells beyond D (and everything when !active) are +0.  Branch-free on
@@ -476,6 +492,13 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
 // the derivation where it is written: the compiler would otherwise hoist it -- and the wait for the kernarg load the
 // control record's address comes from -- to the top of the kernel.
 constexpr int kRunBehindCtlBytes = 256;
+// the control records of chain `chain` (ChainGeometry); pinned where it is written, for the same reason
+__device__ __forceinline__ const StepCtl* chain_ctl(const StepCtl* ctl_in, int chain)
+{
+    unsigned long long c = (unsigned long long)ctl_in;
+    asm volatile("" : "+s"(c)::"memory");
+    return reinterpret_cast<const StepCtl*>(c + (unsigned long long)chain * 512ull);
+}
 __device__ __forceinline__ const RunInfo* run_record_behind(const StepCtl* ctl_in, int which)
 {
     unsigned long long c = (unsigned long long)ctl_in;
@@ -488,7 +511,8 @@ __device__ __forceinline__ const RunInfo* run_record_behind(const StepCtl* ctl_i
 // everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
 struct HotBits
 {
-    // (bit 26: full-step kernels' position-buffer parity; bit 27: the one-entry-per-draw jump table exists)
+    // (bit 26: full-step kernels' position-buffer parity; bit 27: the one-entry-per-draw jump table exists;
+    //  bits 28-31: full-step kernels: chains - 1)
     static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save,
                                              int draw_parity, int draw_wave, int direct_jump)
     {
@@ -552,7 +576,7 @@ template <class T, int MAXR>
 __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const JumpTables& tab, const StepCtl* ctl_ptr, bool block_barrier,
                                                DrawRec<T>* write0, DrawRec<T>* write1, int colours, int shard_begin, int shard_count,
                                                int group_first, int group_walkers, int lane, bool black_only = false,
-                                               const RunInfo* trickle_run = nullptr, int run_behind_ctl = -1)
+                                               const RunInfo* trickle_run = nullptr, int run_behind_ctl = -1, int ctl_chain = 0)
 {
 #ifdef MCMCPP_STAMPS
     unsigned long long dstamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -597,6 +621,7 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const J
         // run_behind_ctl >= 0: the run record's address follows from the control record's (run_record_behind); derived
         // HERE, behind the table loads above -- the control record's address is not among the preloaded arguments, and
         // an address computed at the top of the kernel puts that cold kernarg miss in front of every wavefront's first loads
+        if (ctl_chain != 0) ctl_ptr = chain_ctl(ctl_ptr, ctl_chain);  // (likewise: the chain's own records, ChainGeometry)
         if (run_behind_ctl >= 0) trickle_run = run_record_behind(ctl_ptr, run_behind_ctl);
         load_records_and_warm_args<T>(ctl_ptr, trickle_run != nullptr ? trickle_run : reinterpret_cast<const RunInfo*>(ctl_ptr), ctl, run);
         if (trickle_run != nullptr) trickle_stored_step(run, ctl, lane);
@@ -1213,6 +1238,10 @@ accepted_reduce_kernel(const uint32_t* partials, int partial_slots, int partial_
                        const RunInfo* run_ptr)
 {
     __shared__ unsigned sums[4];
+    // (blockIdx.y: the chain, see ChainGeometry)
+    partials += (size_t)blockIdx.y * (size_t)partial_slots * 2 * (size_t)partial_waves;
+    ctl_after = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_after) + (size_t)blockIdx.y * kCtlChainStride);
+    run_ptr = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(run_ptr) + (size_t)blockIdx.y * kCtlChainStride);
     const RunInfo run = *run_ptr;
     if (run.accepted_per_step == nullptr) return;
     const uint64_t done = ctl_after->step_in_run;
