@@ -138,25 +138,27 @@ def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch}
 
 
-def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, reps):
-    """One of the other single-GPU configurations: `reps` runs of `batch` ensemble steps (nothing stored), with its roofline."""
-    s = capi.HipSampler(W, D, calc, params, seed=0, device=device)
-    pos = workloads.init_positions(W, D, salt=0)
+def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1):
+    """One of the other single-GPU configurations: runs of `batch` ensemble steps (nothing stored) for about `seconds`,
+    with its roofline.  chains > 1: that many independent ensembles (seeds 0, 1, ...) stepped by the same launches."""
+    s = capi.HipSampler(W, D, calc, params, seed=0, device=device, num_chains=chains)
+    pos = np.stack([workloads.init_positions(W, D, salt=k) for k in range(chains)]) if chains > 1 else workloads.init_positions(W, D, salt=0)
     s.set_state(pos, s.calc_logp(pos))
     s.run(1, interval=batch, save_chain=False)
     accepted = 0
-    gpu_ms, launches = 0.0, 0
+    gpu_ms, launches, reps = 0.0, 0, 0
     t0 = time.perf_counter()
-    for _ in range(reps):
+    while time.perf_counter() - t0 < seconds:
         _, acc = s.run(1, interval=batch, save_chain=False)
         accepted += int(acc.sum())
         ms, nl = s.last_run_timing()
         gpu_ms += ms
         launches += nl
+        reps += 1
     dt = time.perf_counter() - t0
-    ws = float(W) * batch * reps
+    ws = float(W) * chains * batch * reps
     s.close()
-    return {"workload": name, "walkers": W, "dims": D, "value": ws / dt, "unit": "walker-steps/s",
+    return {"workload": name, "walkers": W, "dims": D, "chains": chains, "value": ws / dt, "unit": "walker-steps/s",
             "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws,
             "roofline": roofline_of(W, D, ws, launches, gpu_ms, kernel)}
 
@@ -412,10 +414,14 @@ def main():
             line["secondary"] = [
                 secondary_config(capi, workloads, local_rank, "C3: 65536 walkers x 32 dims, Rosenbrock log-posterior, StretchMove, fp64; "
                                  "runs of 1000 ensemble steps, nothing stored", 65536, 32, capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05],
-                                 "stretch_half_step_kernel<double, RosenbrockFn, EPL=2, LPW=16>", 1000, 4),
+                                 "stretch_half_step_kernel<double, RosenbrockFn, EPL=2, LPW=16>", 1000),
                 secondary_config(capi, workloads, local_rank, "C5's ensemble on ONE GPU: 131072 walkers x 64 dims, isotropic Gaussian, "
                                  "StretchMove, fp64; runs of 500 ensemble steps, nothing stored", 131072, 64, capi.CALC_ISO_GAUSSIAN, None,
-                                 "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>", 500, 4),
+                                 "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>", 500),
+                secondary_config(capi, workloads, local_rank, "C4 on ONE GPU: 8 independent chains (seeds 0..7) of 16384 walkers x 32 dims, correlated "
+                                 "Gaussian, StretchMove, fp64, stepped by the same launches (mcmcpp_hip_config.num_chains = 8); runs of 2000 "
+                                 "ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
+                                 "stretch_full_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>", 2000, chains=8),
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)

@@ -80,7 +80,7 @@ __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, co
 // 16 preloaded dwords; what they displaced is derived: the accepted counters lie right behind the two log-posterior
 // buffers ([2][W] elements, then [W] counters: one allocation), and the run record kRunBehindCtlBytes behind the
 // first control record.
-// (run_record_behind, stretch_kernel.hpp)
+// (kRunBehindCtlBytes, stretch_kernel.hpp)
 
 template <class T, class Calc, int EPL, int LPW>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
@@ -93,12 +93,15 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
     const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
     const void* const draws_chain0 = hot_draws;
-    hot_draws += (size_t)chain * 4 * (size_t)h_n;
-    hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
-    hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
-    hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
-    // (the control record's address is not among the preloaded arguments: its chain offset is applied where it is used, chain_ctl)
-    hot_run = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(hot_run) + (size_t)chain * kCtlChainStride);
+    if (__builtin_expect(chain != 0, 0))  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
+    {
+        hot_draws += (size_t)chain * 4 * (size_t)h_n;
+        hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
+        hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
+        hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
+        // (the control record's address is not among the preloaded arguments: its chain offset travels as a load offset)
+        hot_run = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(hot_run) + (size_t)chain * kCtlChainStride);
+    }
     const int h_dims = (int)(hot_bits & 0xFFFu);
     const bool vec_ok = ((hot_bits >> 21) & 1u) != 0;
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
@@ -196,8 +199,8 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     // a microsecond each; issued one by one where first needed they delayed the calculator by about that much).
     StepCtl ctl;  // wave-uniform
     RunInfo run;
-    const StepCtl* const ctl_mine = chain_ctl(hot_ctl_in, chain);
-    load_records_and_warm_args<T>(ctl_mine, hot_run, ctl, run);
+    load_records_and_warm_args<T>(hot_ctl_in, (unsigned)chain * (unsigned)kCtlChainStride, hot_run, 0u, ctl, run);
+    const StepCtl* const ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(hot_ctl_in) + (size_t)chain * kCtlChainStride);
 
     // ---- in its shadow: the calculator's tables, the hand-over to the next launch ----
     const bool has_block_scratch = Calc::block_scratch_elems(h_dims) != 0;
@@ -363,10 +366,13 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
     const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
     const void* const draws_chain0 = hot_draws;
-    hot_draws += (size_t)chain * 4 * (size_t)h_n;
-    hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
-    hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
-    hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
+    if (__builtin_expect(chain != 0, 0))  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
+    {
+        hot_draws += (size_t)chain * 4 * (size_t)h_n;
+        hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
+        hot_pos_b += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;
+        hot_logp_a = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp_a) + (size_t)chain * logp_chain_stride_bytes<T>(h_n));
+    }
     const int h_use_ctl_save = (int)((hot_bits >> 23) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
     const bool h_flip = ((hot_bits >> 26) & 1u) != 0;
@@ -385,7 +391,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
-        // (the run record's address is derived from the control record's, where it is needed: run_record_behind)
+        // (the run record is read at an offset from the control record's address, where it is needed)
         full_step_draw_wave<T>(a, jump_tables_behind(draws_chain0, h_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in, nullptr, false, dn_red, h_n, sh_begin,
                                sh_count, kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0, chain);
         return;
@@ -452,8 +458,10 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
     StepCtl ctl;
     RunInfo run;
-    const StepCtl* const ctl_mine = chain_ctl(hot_ctl_in, chain);  // (the chain's own records: derived here, where a wait is free)
-    load_records_and_warm_args<T>(ctl_mine, run_record_behind(ctl_mine, h_flip ? 1 : 0), ctl, run);
+    // (the chain's own records, the run record kRunBehindCtlBytes behind the first control record: offsets of the batch's loads)
+    load_records_and_warm_args<T>(hot_ctl_in, (unsigned)chain * (unsigned)kCtlChainStride, hot_ctl_in,
+                                  (unsigned)chain * (unsigned)kCtlChainStride + (unsigned)kRunBehindCtlBytes - (h_flip ? (unsigned)sizeof(StepCtl) : 0u), ctl, run);
+    const StepCtl* const ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(hot_ctl_in) + (size_t)chain * kCtlChainStride);
     if (blockIdx.x == 0 && threadIdx.x == 0) hand_over_full<T>(a, ctl, run, const_cast<StepCtl*>(ctl_mine) + (h_flip ? -1 : 1));
     long long save_slot = -1;
     if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval) save_slot = (run.chain_slot_base + ctl.chain_slot) & run.slot_mask;

@@ -124,7 +124,8 @@ __device__ __forceinline__ JumpTables jump_tables_behind(const void* draws_base,
 //   draw records               [chains][2][2][n], then the shared jump tables
 //   partial accepted counts    [chains][partial_slots][2][partial_waves]
 // The chains differ in their seed (seed + chain: same stream increment, hence the same jump tables).
-constexpr int kCtlChainStride = 512;  // (chain_ctl spells the number out)
+constexpr int kCtlChainStride = 512;
+constexpr int kRunBehindCtlBytes = 256;
 constexpr int kMaxChains = 16;  // (four hot bits)
 template <class T>
 __host__ __device__ inline size_t logp_chain_stride_bytes(int n) { return (size_t)4 * (size_t)n * sizeof(T) + (size_t)2 * (size_t)n * sizeof(uint32_t); }
@@ -373,8 +374,13 @@ struct LdsLayout
 // wait.  Inline assembly on purpose: as plain loads the compiler issues each where it is first needed -- three
 // dependent cold misses in a row along a wavefront's path -- and is free to hoist a wait in front of vector loads
 // that should have gone out first (it did: in front of the second round trip).
+// The records are read at base + offset with the offsets in SGPRs (the s_load's own offset operand): a base that comes
+// from the kernarg segment -- the control record's address is not among the preloaded arguments -- then needs no
+// arithmetic outside this batch, so nothing can drag the wait for it in front of vector loads issued earlier.  (Pointer
+// arithmetic on such a base, even pinned with an empty asm, was scheduled ahead of the matrix loads: 5.63 -> 6.01 us.)
 template <class T>
-__device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_ptr, const RunInfo* run_ptr, StepCtl& ctl, RunInfo& run)
+__device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_ptr, unsigned ctl_off, const void* run_ptr, unsigned run_off, StepCtl& ctl,
+                                                           RunInfo& run)
 {
     static_assert(64 + sizeof(HalfStepArgs<T>) > 0x180 && 64 + sizeof(HalfStepArgs<T>) <= 0x200, "adjust the lines touched below");
     static_assert(sizeof(StepCtl) == 64 && sizeof(RunInfo) == 64, "one s_load_dwordx16 each");
@@ -389,9 +395,10 @@ __device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_pt
     const unsigned long long ctl_addr = uniform(ctl_ptr), run_addr = uniform(run_ptr);
     v16u c, r;
     unsigned t1, t2, t3, t4, t5, t6, t7;
+    const unsigned off_c = __builtin_amdgcn_readfirstlane(ctl_off), off_r = __builtin_amdgcn_readfirstlane(run_off);
     asm volatile(
-        "s_load_dwordx16 %0, %9, 0x0\n\t"
-        "s_load_dwordx16 %1, %10, 0x0\n\t"
+        "s_load_dwordx16 %0, %9, %12\n\t"
+        "s_load_dwordx16 %1, %10, %13\n\t"
         "s_load_dword %2, %11, 0x40\n\t"
         "s_load_dword %3, %11, 0x80\n\t"
         "s_load_dword %4, %11, 0xc0\n\t"
@@ -401,10 +408,16 @@ __device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_pt
         "s_load_dword %8, %11, 0x1c0\n\t"
         "s_waitcnt lgkmcnt(0)"
         : "=&s"(c), "=&s"(r), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7)
-        : "s"(ctl_addr), "s"(run_addr), "s"(k)
+        : "s"(ctl_addr), "s"(run_addr), "s"(k), "s"(off_c), "s"(off_r)
         : "memory");
     ctl = __builtin_bit_cast(StepCtl, c);
     run = __builtin_bit_cast(RunInfo, r);
+}
+
+template <class T>
+__device__ __forceinline__ void load_records_and_warm_args(const StepCtl* ctl_ptr, const RunInfo* run_ptr, StepCtl& ctl, RunInfo& run)
+{
+    load_records_and_warm_args<T>(ctl_ptr, 0u, run_ptr, 0u, ctl, run);
 }
 
 // One random draw of one walker: task k of the walker at position i of the half (draw 3*i + k of the
@@ -487,25 +500,8 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
     }
 }
 
-// The run record lies kRunBehindCtlBytes behind the first of the two control records (one allocation).  A kernel short
-// of preloaded arguments derives its address from the control record it reads (record `which`: 0 or 1).  The asm pins
-// the derivation where it is written: the compiler would otherwise hoist it -- and the wait for the kernarg load the
-// control record's address comes from -- to the top of the kernel.
-constexpr int kRunBehindCtlBytes = 256;
-// the control records of chain `chain` (ChainGeometry); pinned where it is written, for the same reason
-__device__ __forceinline__ const StepCtl* chain_ctl(const StepCtl* ctl_in, int chain)
-{
-    unsigned long long c = (unsigned long long)ctl_in;
-    asm volatile("" : "+s"(c)::"memory");
-    return reinterpret_cast<const StepCtl*>(c + (unsigned long long)chain * 512ull);
-}
-__device__ __forceinline__ const RunInfo* run_record_behind(const StepCtl* ctl_in, int which)
-{
-    unsigned long long c = (unsigned long long)ctl_in;
-    asm volatile("" : "+s"(c)::"memory");
-    return reinterpret_cast<const RunInfo*>(c - (unsigned long long)which * sizeof(StepCtl) + (unsigned long long)kRunBehindCtlBytes);
-}
-
+// The run record lies kRunBehindCtlBytes behind the first of the two control records (one allocation): a kernel short
+// of preloaded arguments reads it at an offset from the control record's address (load_records_and_warm_args).
 // Hot scalars of a launch, packed so that the arguments every wavefront needs before its first memory
 // access fit the 16 dwords the command processor preloads into SGPRs (-amdgpu-kernarg-preload-count=16);
 // everything else stays in the by-value HalfStepArgs and is fetched from the kernarg segment on demand.
@@ -618,13 +614,16 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const J
     StepCtl ctl;
     {
         RunInfo run;  // (only wanted when this wavefront also forwards stored steps; otherwise the control record twice)
-        // run_behind_ctl >= 0: the run record's address follows from the control record's (run_record_behind); derived
-        // HERE, behind the table loads above -- the control record's address is not among the preloaded arguments, and
-        // an address computed at the top of the kernel puts that cold kernarg miss in front of every wavefront's first loads
-        if (ctl_chain != 0) ctl_ptr = chain_ctl(ctl_ptr, ctl_chain);  // (likewise: the chain's own records, ChainGeometry)
-        if (run_behind_ctl >= 0) trickle_run = run_record_behind(ctl_ptr, run_behind_ctl);
-        load_records_and_warm_args<T>(ctl_ptr, trickle_run != nullptr ? trickle_run : reinterpret_cast<const RunInfo*>(ctl_ptr), ctl, run);
-        if (trickle_run != nullptr) trickle_stored_step(run, ctl, lane);
+        // (the chain's own records, ChainGeometry: ctl_chain control-record strides further; the run record either given or,
+        //  run_behind_ctl >= 0, kRunBehindCtlBytes behind the first control record -- all as offsets of the batch's loads)
+        const unsigned ctl_off = (unsigned)ctl_chain * (unsigned)kCtlChainStride;
+        const bool wants_run = trickle_run != nullptr || run_behind_ctl >= 0;
+        if (run_behind_ctl >= 0)
+            load_records_and_warm_args<T>(ctl_ptr, ctl_off, ctl_ptr, ctl_off + (unsigned)kRunBehindCtlBytes - (unsigned)run_behind_ctl * (unsigned)sizeof(StepCtl), ctl, run);
+        else
+            load_records_and_warm_args<T>(ctl_ptr, ctl_off, trickle_run != nullptr ? static_cast<const void*>(trickle_run) : static_cast<const void*>(ctl_ptr),
+                                          trickle_run != nullptr ? 0u : ctl_off, ctl, run);
+        if (wants_run) trickle_stored_step(run, ctl, lane);
     }
     MCMCPP_DSTAMP(1, true);
     if (block_barrier) __syncthreads();  // keep the workgroup barrier count whole
