@@ -16,6 +16,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <future>
 #include <vector>
 
 #include "ChainBlock.h"
@@ -57,6 +58,7 @@ public:
     }
     ~Chain()
     {
+        if (nextBlock.valid()) delete nextBlock.get();
         for (ChainBlock<ParamType>* b : blocks) delete b;
     }
     Chain(const Chain&) = delete;
@@ -100,6 +102,10 @@ public:
     {
         for (std::int64_t k = 0; k < count; ++k) incrementChainStep();
     }
+
+    /// Obtain every block one block ahead of its use, on a helper thread (the samplers switch this on; off by default so
+    /// that a Chain used alone never starts a thread).
+    void setBlockPrefetch(bool on) { prefetchBlocks = on; }
 
     // ---- bookkeeping -------------------------------------------------------------------------------------
     std::int64_t getStoredStepCount() const { return stepCount; }
@@ -163,18 +169,45 @@ private:
             const std::int64_t lo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
             if (lo + want > maxSteps) want = maxSteps - lo;
             if (want < 1) return nullptr;
-            ChainBlock<ParamType>* nb = new ChainBlock<ParamType>(want, cellsPerStep, blockMemory);
+            // A block is obtained one block ahead, on a thread of its own, while the sampler fills the current one: pinned
+            // memory from a provider costs some 35 ms per 256 MiB block, heap memory as much in first-touch page faults
+            // (which that thread takes by writing to every page).
+            ChainBlock<ParamType>* nb = nullptr;
+            if (nextBlock.valid())
+            {
+                nb = nextBlock.get();
+                if (nb && nb->capacity() != want)
+                {
+                    delete nb;
+                    nb = nullptr;
+                }
+            }
+            if (!nb) nb = new ChainBlock<ParamType>(want, cellsPerStep, blockMemory);
             if (!nb->valid())
             {
                 delete nb;
                 return nullptr;
             }
             blocks.push_back(nb);
+            if (prefetchBlocks)
+            {
+                const std::int64_t nextLo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
+                std::int64_t nextWant = stepsPerBlock;
+                if (nextLo + nextWant > maxSteps) nextWant = maxSteps - nextLo;
+                if (nextWant >= 1)
+                {
+                    const std::int64_t cells = cellsPerStep;
+                    const Detail::BlockMemory mem = blockMemory;
+                    nextBlock = std::async(std::launch::async, [nextWant, cells, mem]() { return new ChainBlock<ParamType>(nextWant, cells, mem, true); });
+                }
+            }
         }
         return blocks[b]->step(stepCount % stepsPerBlock);
     }
 
     std::vector<ChainBlock<ParamType>*> blocks;
+    std::future<ChainBlock<ParamType>*> nextBlock;  ///< the block behind the last one, being obtained
+    bool prefetchBlocks = false;                    ///< obtain blocks one ahead on a helper thread (setBlockPrefetch)
     Detail::BlockMemory blockMemory;
     int walkerCount;
     int cellsPerWalker;

@@ -39,7 +39,9 @@ template <class ParamType>
 class ChainBlock
 {
 public:
-    ChainBlock(std::int64_t stepsInBlock, std::int64_t cellsInStep, const Detail::BlockMemory& mem = Detail::BlockMemory())
+    /// touchPages: write to every page of a heap block now (the Chain does this on the thread that obtains blocks ahead of
+    /// their use, so that the first-touch page faults -- about 45 ms per 256 MiB -- are not paid by whoever fills the block)
+    ChainBlock(std::int64_t stepsInBlock, std::int64_t cellsInStep, const Detail::BlockMemory& mem = Detail::BlockMemory(), bool touchPages = false)
         : capacitySteps(stepsInBlock), cellsPerStep(cellsInStep), usedSteps(0), cells(nullptr), releaseFn(nullptr)
     {
         const std::size_t bytes = static_cast<std::size_t>(capacitySteps) * static_cast<std::size_t>(cellsPerStep) * sizeof(ParamType);
@@ -49,6 +51,8 @@ public:
             releaseFn = mem.release;
         else if (posix_memalign(&p, 64, bytes ? bytes : 64) != 0)
             p = nullptr;
+        else if (touchPages)
+            for (std::size_t off = 0; off < bytes; off += 4096) static_cast<volatile char*>(p)[off] = 0;
         cells = static_cast<ParamType*>(p);
     }
     ~ChainBlock()

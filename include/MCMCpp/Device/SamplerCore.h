@@ -49,9 +49,10 @@ public:
     SamplerCore(int randSeed, long long stream, int numWalker, int numParameter, const Mover& move,
                 unsigned long long maxChainSizeBytes, PostStepAction* stepAct, const Placement& where = Placement::fromEnvironment())
         : stepAction(stepAct),
-          markovChain(numWalker, numParameter, maxChainSizeBytes, Chain::Detail::DefaultBlockBytes, Chain::Detail::BlockMemory(&pinnedObtain, &pinnedRelease)),
+          markovChain(numWalker, numParameter, maxChainSizeBytes, Chain::Detail::DefaultBlockBytes, chainMemory()),
           moveProposer(move), numParams(numParameter), numWalkers(numWalker), initialPlacementCounted(false)
     {
+        markovChain.setBlockPrefetch(true);
         assert(numWalkers % 2 == 0);             // EnsembleSampler.h:207
         assert(numWalkers > (2 * numParams));    // EnsembleSampler.h:208
         moveProposer.setPrng(randSeed, stream);  // EnsembleSampler.h:217 / RedBlkUpdater.h:86
@@ -212,6 +213,17 @@ public:
 protected:
     static void* pinnedObtain(unsigned long long bytes) { return mcmcpp_hip_host_alloc(bytes); }
     static void pinnedRelease(void* p) { mcmcpp_hip_host_free(p); }
+    /// Chain blocks come from the heap (stored steps pass through the library's pinned staging ring and are copied out by
+    /// the host while the launches continue) unless MCMCPP_CHAIN_MEMORY=pinned asks for pinned host memory, into which the
+    /// step launches write stored steps directly.  Measured at C2 (tools/bench_facade.cpp): pinned blocks win
+    /// when the memory already exists (a chain that is reset and refilled); obtaining them costs as much as the page
+    /// faults of fresh heap memory but stalls the launches while it lasts, so a growing chain is faster on the heap.
+    static Chain::Detail::BlockMemory chainMemory()
+    {
+        const char* v = std::getenv("MCMCPP_CHAIN_MEMORY");
+        if (v && v[0] == 'p' && v[1] == 'i') return Chain::Detail::BlockMemory(&pinnedObtain, &pinnedRelease);
+        return Chain::Detail::BlockMemory();
+    }
 
     PostStepAction* stepAction;
     ChainType markovChain;
