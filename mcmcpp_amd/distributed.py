@@ -14,6 +14,8 @@ The stepping itself is delegated to a *shard backend*: `HipShardBackend` (the pr
 this rank's GPU, positions in a torch CUDA tensor shared with RCCL) or any object with the same five methods
 (the CPU tests drive the same code with an oracle-based backend over gloo).
 """
+import contextlib
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -42,25 +44,34 @@ def shard_bounds(n_half, world, rank):
 
 
 class HipShardBackend:
-    """This rank's slice on its GPU: positions live in a torch CUDA tensor handed to libmcmcpp_hip.so as
-    `device_positions`, launches go to torch's current stream so that RCCL collectives issued through
-    torch.distributed are ordered with them."""
+    """This rank's slice on its GPU, for callers that bring their own exchange (the product path is a handle with an
+    RCCL communicator: capi.HipSampler(comm_world=...), whose run() enqueues launches and exchanges itself).  Positions
+    live in a torch CUDA tensor handed to libmcmcpp_hip.so as `device_positions`; launches and the collectives issued
+    through torch.distributed go to ONE dedicated non-blocking stream (not torch's legacy default stream, which would
+    serialise with every blocking stream of the process), so they are ordered with each other and with nothing else."""
 
     def __init__(self, W, D, calc_id, params, seed, stream, dtype, begin, count, device):
         from . import capi
         self.capi = capi
         t = torch.float64 if dtype == capi.F64 else torch.float32
         self.pos = torch.empty((W, D), dtype=t, device=device)
+        self.stream = torch.cuda.Stream(device=self.pos.device)
         self.sampler = capi.HipSampler(W, D, calc_id, params, seed=seed, stream=stream, dtype=dtype,
                                        device=self.pos.device.index, shard_begin=begin, shard_count=count,
-                                       device_positions=self.pos.data_ptr(),
-                                       hip_stream=torch.cuda.current_stream(self.pos.device).cuda_stream)
+                                       device_positions=self.pos.data_ptr(), hip_stream=self.stream.cuda_stream)
 
     def set_state(self, pos, logp):
         self.sampler.set_state(pos, logp)
 
     def half_step(self, color):
         self.sampler.half_step_async(color)
+
+    def exchange_context(self):
+        """Collectives of the exchange are issued inside this context: on the stream the half-steps run on."""
+        return torch.cuda.stream(self.stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
 
     def positions(self):
         return self.pos
@@ -95,8 +106,10 @@ class SplitEnsemble:
         pos = self.backend.positions()
         half = pos[color * self.n:(color + 1) * self.n]
         mine = half[self.begin:self.begin + self.count]
-        # in place: the input is this rank's slice of the output (ncclAllGather's in-place form)
-        dist.all_gather_into_tensor(half.reshape(-1), mine.reshape(-1), group=self.group)
+        # in place: the input is this rank's slice of the output (ncclAllGather's in-place form); on the backend's stream
+        ctx = self.backend.exchange_context() if hasattr(self.backend, "exchange_context") else contextlib.nullcontext()
+        with ctx:
+            dist.all_gather_into_tensor(half.reshape(-1), mine.reshape(-1), group=self.group)
 
     def step(self):
         """One ensemble step: red half-step, exchange, black half-step, exchange (EnsembleSampler.h:341-354)."""
@@ -110,15 +123,21 @@ class SplitEnsemble:
         [n_saved, W, D] as a tensor on the positions' device (every rank holds the full replica)."""
         pos = self.backend.positions()
         chain = torch.empty((n_saved, self.W, self.D), dtype=pos.dtype, device=pos.device) if save_chain else None
+        ctx = self.backend.exchange_context() if hasattr(self.backend, "exchange_context") else contextlib.nullcontext()
         for k in range(n_saved):
             for _ in range(interval):
                 self.step()
             if chain is not None:
-                chain[k].copy_(pos)
+                with ctx:
+                    chain[k].copy_(pos)
+        if hasattr(self.backend, "synchronize"):
+            self.backend.synchronize()
         return chain
 
     def gather_state(self):
         """Full (positions, logp, n_accept) on every rank."""
+        if hasattr(self.backend, "synchronize"):
+            self.backend.synchronize()
         logp, nacc = self.backend.local_state()
         pos = self.backend.positions()
         logp_t = torch.as_tensor(np.ascontiguousarray(logp)).to(pos.device)

@@ -187,6 +187,25 @@ int main()
         }
         CHECK(ProviderCalls::released == 3);  // (heap blocks are not handed to the provider's release)
         ProviderCalls::fail = false;
+        // blocks obtained one ahead on a helper thread (what the samplers switch on): same contents; a block that was
+        // obtained ahead and never used is returned when the chain goes
+        ProviderCalls::obtained = ProviderCalls::released = 0;
+        {
+            ChainD c(W, D, 12 * stepBytes, 4 * stepBytes, MCMC::Chain::Detail::BlockMemory(&ProviderCalls::obtain, &ProviderCalls::release));
+            c.setBlockPrefetch(true);
+            fill(c, 5, W, D);
+            long s = 0;
+            for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != c.getStepIteratorEnd(); ++it, ++s)
+                CHECK((*it)[W * D - 1] == cell(s, W - 1, D - 1));
+            CHECK(s == 5);
+        }
+        CHECK(ProviderCalls::obtained == 3 && ProviderCalls::released == 3);
+        {
+            ChainD c(W, D, 12 * stepBytes, 4 * stepBytes);  // heap blocks, touched ahead
+            c.setBlockPrefetch(true);
+            fill(c, 12, W, D);
+            CHECK((*c.getStepIteratorBegin())[5] == cell(0, 1, 2) && c.remainingSteps() == 0);
+        }
     }
     {
         // The reference's own plumbing test at scale (/root/reference/test/sequential/InnerBenchmark/src/main.cpp:9-13,32:

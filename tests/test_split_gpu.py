@@ -160,6 +160,53 @@ def test_whole_ensemble_handle_on_the_legacy_default_stream():
     np.testing.assert_array_equal(chain, want_chain)
 
 
+_TWO_RANKS = r'''
+import os, sys, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from mcmcpp_amd import capi
+from oracle import pyoracle as po
+rank, world, idfile = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+if rank == 0:
+    open(idfile + ".tmp", "wb").write(capi.comm_unique_id()); os.rename(idfile + ".tmp", idfile)
+else:
+    while not os.path.exists(idfile): time.sleep(0.05)
+cid = open(idfile, "rb").read()
+W, D = 8192, 64
+orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=3)
+pos = po.init_positions(po.F64, W, D, salt=1); logp = orc.logp(pos); orc.set_state(pos, logp)
+for scheme in ("1", "0"):
+    os.environ["MCMCPP_HIP_COMM_FULL_STEP"] = scheme
+    orc.set_state(pos, logp)
+    want, want_acc = orc.run(5, interval=3, mode=po.MODE_COUNTER, threads=4)
+    hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=3, device=rank, comm_world=world, comm_rank=rank, comm_id=cid)
+    hip.set_state(pos, logp)
+    chain, acc = hip.run(5, interval=3)
+    assert np.array_equal(acc, want_acc), "accepted counts differ"
+    assert np.array_equal(chain, want), "chains differ"
+    for got, wanted in zip(hip.get_state(), orc.get_state()):
+        assert np.array_equal(got, wanted)
+    c = hip.counters()
+    assert c["near_ties"] == 0 and c["redraws"] == 0
+    hip.close()
+print("SPLIT_RANK_%%d_OK" %% rank)
+'''
+
+
+def test_split_ensemble_over_two_gpus_through_the_c_abi(tmp_path):
+    """One ensemble split over TWO GPUs, exchanged over RCCL by the library (both schemes), against the oracle.  Needs a box
+    with two GPUs: the driver's one-GPU test box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    idfile = str(tmp_path / "rccl_id")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANKS % {"root": ROOT}, str(r), "2", idfile], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (out, err) in enumerate(outs):
+        assert "SPLIT_RANK_%d_OK" % r in out, out[-2000:] + err[-4000:]
+
+
 _SINGLE_RANK = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
