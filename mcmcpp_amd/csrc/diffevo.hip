@@ -72,14 +72,14 @@ public:
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
         HIP_TRY(hipMalloc(&d_ctl, sizeof(DeCtl) * 4));
         HIP_TRY(hipMalloc(&d_shared, sizeof(DeShared)));
-        HIP_TRY(hipMalloc(&d_cand, sizeof(DeCand) * 2 * kDeMaxCand));
-        HIP_TRY(hipMalloc(&d_resolved, sizeof(DeResolved) * 2));
-        HIP_TRY(hipMemset(d_resolved, 0, sizeof(DeResolved) * 2));
+        // a half-step has about D + 3 bad positions (one per walker collides with probability 1/n, (D+3)n positions)
+        bad_capacity = 8 * (D + 3) + 512;
+        HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * 2 * (size_t)bad_capacity));
+        HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * 2 * (size_t)bad_capacity));
         HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * (size_t)n));
         HIP_TRY(hipMalloc(&d_run, sizeof(DeRunInfo)));
         HIP_TRY(hipMalloc(&d_step, sizeof(DeStepCtl) * 2));
         HIP_TRY(hipMemset(d_shared, 0, sizeof(DeShared)));
-        HIP_TRY(hipMemset(d_cand, 0, sizeof(DeCand) * 2 * kDeMaxCand));
         for (int k = 0; k < 2; ++k)
         {
             HIP_TRY(hipEventCreate(&ev_t0[k]));
@@ -87,7 +87,7 @@ public:
         }
         // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
         {
-            // MCMCPP_HIP_DE_FIND_WALKERS: batches of kDeFindBatch walkers one finder wavefront looks at (read once, here)
+            // MCMCPP_HIP_DE_FIND_WALKERS: runs of kDeScanRun stream positions one scanning lane takes (read once, here)
             const char* v = std::getenv("MCMCPP_HIP_DE_FIND_WALKERS");
             knob_walkers_per_find_wave = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 1;
             if (knob_walkers_per_find_wave < 1) knob_walkers_per_find_wave = 1;
@@ -116,7 +116,10 @@ public:
         pcg_seed(c.seed, c.stream, &state0, &inc);
         const unsigned per = (unsigned)D + 3u;
         {
-            std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256), small((size_t)D + kDeRaw + 1);
+            scan_positions = (int)per * n + kDeMaxShift + 1;
+            const size_t scan_lanes = ((size_t)scan_positions + kDeScanRun - 1) / kDeScanRun;
+            std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256), small((size_t)(D > kDeMaxShift ? D : kDeMaxShift) + 2);
+            std::vector<Affine128> slo(256), shi((scan_lanes + 255) / 256);
             Affine128 id;
             id.mult = make_u128(0, 1);
             id.plus = make_u128(0, 0);
@@ -125,6 +128,14 @@ public:
             for (size_t j = 1; j < lo.size(); ++j) lo[j] = compose(step_u, lo[j - 1]);
             for (size_t m = 1; m < hi.size(); ++m) hi[m] = compose(step_b, hi[m - 1]);
             for (size_t j = 1; j < small.size(); ++j) small[j] = compose(step_1, small[j - 1]);
+            const Affine128 step_r = pcg_jump(inc, kDeScanRun), step_rb = pcg_jump(inc, (unsigned __int128)kDeScanRun * 256u);
+            slo[0] = shi[0] = id;
+            for (size_t j = 1; j < slo.size(); ++j) slo[j] = compose(step_r, slo[j - 1]);
+            for (size_t m = 1; m < shi.size(); ++m) shi[m] = compose(step_rb, shi[m - 1]);
+            HIP_TRY(hipMalloc(&d_scan_lo, sizeof(Affine128) * slo.size()));
+            HIP_TRY(hipMalloc(&d_scan_hi, sizeof(Affine128) * shi.size()));
+            HIP_TRY(hipMemcpy(d_scan_lo, slo.data(), sizeof(Affine128) * slo.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(d_scan_hi, shi.data(), sizeof(Affine128) * shi.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMalloc(&d_jump_lo, sizeof(Affine128) * lo.size()));
             HIP_TRY(hipMalloc(&d_jump_hi, sizeof(Affine128) * hi.size()));
             HIP_TRY(hipMalloc(&d_jump_small, sizeof(Affine128) * small.size()));
@@ -232,8 +243,11 @@ public:
         a.calc_params = d_params;
         a.ctl = d_ctl;
         a.shared = d_shared;
-        a.cand = d_cand;
-        a.resolved = d_resolved;
+        a.bad = d_bad;
+        a.bad_capacity = bad_capacity;
+        a.scan_positions = scan_positions;
+        a.scan_hi = d_scan_hi;
+        a.scan_lo = d_scan_lo;
         a.recs = d_recs;
         a.run = d_run;
         a.step_ctl = d_step;
@@ -254,21 +268,20 @@ public:
         const int per_block = (64 / lpw) * kWavesPerBlock;
         update_blocks = (n + per_block - 1) / per_block;
         record_blocks = (n + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-        // finders: a wavefront per walker, about eight walkers per wavefront
-        find_blocks = (n + kDeFindBatch * knob_walkers_per_find_wave * kWavesPerBlock - 1) / (kDeFindBatch * knob_walkers_per_find_wave * kWavesPerBlock);
-        if (find_blocks > 4096) find_blocks = 4096;
-        if (find_blocks < 1) find_blocks = 1;
+        // scanners: a lane per kDeScanRun stream positions (knob: that many runs per lane)
+        {
+            const long lanes = ((long)scan_positions + kDeScanRun - 1) / kDeScanRun;
+            const long per_wg = 64L * kWavesPerBlock * knob_walkers_per_find_wave;
+            find_blocks = (int)((lanes + per_wg - 1) / per_wg);
+            if (find_blocks < 1) find_blocks = 1;
+        }
 
         // Priming: the planners run one half-step (records) and two half-steps (candidates) ahead of the updates.  Two
         // planning-only launches bring them there from the stream position the ring holds for the coming half-step.
         run_touched = true;
-        {
-            // (the candidate counters and the finders' tickets; the error flags stay)
-            HIP_TRY(hipMemsetAsync(d_shared, 0, offsetof(DeShared, error), stream));
-            HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(d_shared) + offsetof(DeShared, finished), 0, sizeof(uint32_t) * 4, stream));
-        }
-        launch_step((int)((half_steps + 2) & 3), /*with_update=*/false, /*with_records=*/false);  // candidates of the coming half-step
-        launch_step((int)((half_steps + 3) & 3), false, true);                                     // its records, candidates of the next
+        HIP_TRY(hipMemsetAsync(d_shared, 0, offsetof(DeShared, error), stream));  // (the bad-position counters; the error flags stay)
+        launch_step((int)((half_steps + 3) & 3), /*with_update=*/false, /*with_records=*/false);  // bad positions of the coming half-step
+        launch_step((int)((half_steps + 3) & 3), false, true);                                     // its records, positions of the next
         HIP_TRY(hipGetLastError());
 
         double gpu_ms = 0.0;
@@ -325,8 +338,8 @@ public:
             have_state = false;
             return fail(MCMCPP_HIP_E_UNSUPPORTED,
                         "differential evolution: the random stream could not be followed (flags %u: 1 = more than %d draws thrown away in one "
-                        "half-step, 2 = more than %d candidates, 4 = one update threw away more than %d draws); the state is undefined, call set_state",
-                        sh.error, kDeMaxShift, kDeMaxCand, kDeWindow - 2);
+                        "half-step, 2 = more than %d possible starts among the bad positions, 4 = one update threw away more than %d draws); the state is undefined, call set_state",
+                        sh.error, kDeMaxShift, kDeMaxEvents, kDeWindow - 2);
         }
         return MCMCPP_HIP_OK;
     }
@@ -504,7 +517,7 @@ private:
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
         for (hipGraphExec_t ex : graph_cache)
             if (ex) (void)hipGraphExecDestroy(ex);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_cand, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_run, d_step, d_resolved};
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_run, d_step, d_bad, d_scan_lo, d_scan_hi};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         for (int k = 0; k < 2; ++k)
@@ -526,7 +539,9 @@ private:
     Diag* d_diag = nullptr;
     DeCtl* d_ctl = nullptr;
     DeShared* d_shared = nullptr;
-    DeResolved* d_resolved = nullptr;
+    DeBad* d_bad = nullptr;
+    Affine128 *d_scan_lo = nullptr, *d_scan_hi = nullptr;
+    int bad_capacity = 0, scan_positions = 0;
     DeRec<T>* d_recs = nullptr;
     DeRunInfo* d_run = nullptr;
     DeStepCtl* d_step = nullptr;
@@ -535,7 +550,7 @@ private:
     bool run_touched = false;
     hipEvent_t ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> graph_cache;
-    DeCand* d_cand = nullptr;
+
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_jump_small = nullptr;
     size_t chain_bytes = 0, acc_count = 0;
     std::vector<uint32_t> acc_host;

@@ -4,25 +4,29 @@
 //   ind1 = engine(n); ind2 = engine(n) until it differs from ind1; D uniform jitters; (Calculator); one exponential
 // i.e. D + 3 draws plus every draw thrown away (by pcg's bounded_rand below its threshold, by the ind2 loop).  The
 // next walker's first draw follows this walker's last, so a walker's place in the stream depends on how many draws
-// all walkers before it threw away -- the reason the reference's loop is sequential.  Whether an update starting
-// at a given stream position throws draws away depends on the stream alone, never on the walkers, so everything that
-// concerns the stream is PLANNED AHEAD of the updates, by extra workgroups of the very launch that updates an earlier
-// half-step.  One launch per half-step h (de_step_kernel), three kinds of workgroup:
+// all walkers before it threw away -- the reason the reference's loop is sequential.  But whether an update that
+// STARTS at a given stream position throws draws away is a property of that position alone (of the two draws there:
+// one below the threshold, or both naming the same walker), never of the walkers: call such a position bad, and E(p)
+// the number of draws an update starting there throws away.  So the stream is PLANNED AHEAD of the updates, by extra
+// workgroups of the very launch that updates an earlier half-step.  One launch per half-step h (de_step_kernel),
+// three kinds of workgroup:
 //   update   half-step h: like the stretch half-step kernel -- first round trip: the walker's 32-byte record (its two
 //            partners, the engine state behind its integer draws, the logarithm of its accept draw), own row,
 //            log-posterior, counter; second round trip: the two partner rows; in its shadow the lanes draw their own
 //            jitters; calculator, accept in place, optional chain store;
-//   records  half-step h + 1: every planning workgroup first sorts the few candidates of that half-step (found one
-//            launch earlier) and walks them in order, r += extra[r] -- the only sequential part, a few dozen steps from
-//            LDS; then one lane per walker finds its shift by a search in that short list, jumps to its place through
-//            three table look-ups, replays its integer draws and leaves the walker's record behind;
-//   find     half-step h + 2 (its base state follows from the walk above): a wavefront per walker k looks at the draws
-//            at (D+3)k + r for every shift r = 0..kDeMaxShift the walkers before it may have caused (lane j makes draw
-//            j), and reports the walker as a candidate when any of those starts would throw a draw away (about
-//            kDeMaxShift + 1 of the n walkers), with its table extra[r].
+//   records  half-step h + 1: every planning workgroup first RESOLVES that half-step from the list of its bad
+//            positions (made one launch earlier): only a bad position p with p mod (D+3) <= 31 can be a walker's start
+//            at all (walker k starts at (D+3)k + r with r, the draws thrown away so far in the half-step, at most
+//            kDeMaxShift); those few are sorted, and the walk "the next start that is bad for the current r" is a
+//            handful of wave ballots (about one event per half-step, whatever n is); then one lane per walker finds its
+//            shift by a search in the event list, jumps to its place through three table look-ups, replays its integer
+//            draws and leaves the walker's record behind;
+//   scan     half-step h + 2 (its base state follows from the resolve above): every stream position the half-step can
+//            reach is drawn ONCE -- a lane jumps to eight consecutive positions' start (two table look-ups) and steps
+//            through them -- and the bad ones (about D + 3 of them) go to that half-step's list with their E.
 // The launches of a run are replayed from a hipGraph; the stream position, the error flags and the per-run counters
 // travel in device memory (DeCtl ring, DeStepCtl).  More than kDeMaxShift thrown-away draws in one half-step (expected:
-// about one, whatever n is) raise a sticky error flag the host turns into a failed run: never a silently different chain.
+// about one) raise a sticky error flag the host turns into a failed run: never a silently different chain.
 //
 // Everything else is the stretch kernels' machinery: the calculator functor with its lane mapping (LPW lanes x EPL
 // elements), rows updated in place (a half only reads the other half), optional store into the device chain.
@@ -35,19 +39,19 @@ namespace mcmcpp
 constexpr int kDeMaxShift = 31;   // largest number of thrown-away draws inside one half-step that is followed exactly
 constexpr int kDeWindow = 32;     // raw draws one update's integer part may consume (2 + up to 30 thrown away: even two
                                   // walkers per half, where every second ind2 collides, overrun once in 1e9 updates)
-constexpr int kDeOverrun = 255;   // DeCand::extra value of a start whose update would not fit that window
-constexpr int kDeRaw = kDeMaxShift + 1 + kDeWindow;
-constexpr int kDeMaxCand = 128;   // candidates per half-step the lists hold (typical: kDeMaxShift + 1)
+constexpr int kDeOverrun = 255;   // E of a start whose update would not fit that window
+constexpr int kDeMaxEvents = 128; // bad positions that can be a walker's start, per half-step (typical: about 32)
+constexpr int kDeScanRun = 8;     // consecutive stream positions one scanning lane steps through
 constexpr int kDeAccSlots = 64;   // counters an ensemble step's accepted proposals are spread over (same-address atomics serialise)
 
 enum : uint32_t
 {
     kDeErrShift = 1u,   // more than kDeMaxShift draws thrown away in one half-step
-    kDeErrCand = 2u,    // more than kDeMaxCand candidates
+    kDeErrCand = 2u,    // more bad positions than the lists hold
     kDeErrWindow = 4u,  // one update threw away more than kDeWindow - 2 draws
 };
 
-// one per half-step, a ring of four (index = half-step & 3): launch h reads the records of h + 1 and h + 2 and writes that of h + 3
+// one per half-step, a ring of four (index = half-step & 3): launch h reads the record of h + 1 and writes that of h + 2
 struct alignas(64) DeCtl
 {
     U128 state;                      // engine state in front of this half-step's first draw
@@ -56,37 +60,27 @@ struct alignas(64) DeCtl
 };
 static_assert(sizeof(DeCtl) == 64, "one line per record");
 
-// candidate counters of the half-steps (index = half-step & 3), the sticky error flags, all in one line
+// bad-position counters of the half-steps (index = half-step & 3), the sticky error flags, all in one line
 struct alignas(64) DeShared
 {
-    uint32_t cand_count[4];
-    uint32_t error;       // kDeErr* bits
-    uint32_t finished[4]; // finder workgroups done with the candidates of half-step (index & 3): the last one resolves them
-    uint32_t pad[7];
+    uint32_t bad_count[4];
+    uint32_t error;  // kDeErr* bits
+    uint32_t pad[11];
 };
 
-// resolved list entry, sorted by k: walkers behind k start shift_after draws late
+// a bad stream position of a half-step: p draws behind the half-step's first, an update starting there throws away e draws
+struct DeBad
+{
+    uint32_t p;
+    uint32_t e;
+};
+
+// resolved list entry (LDS), in walker order: walkers behind k start shift_after draws late
 struct DePlan
 {
     uint32_t k;
     uint32_t shift_after;
 };
-// The candidates of one half-step, resolved: sorted, walked (r += extra[r]).  Made by the finder workgroup that finishes
-// last, read by the planners of the next launch (two buffers, index = half-step & 1).
-struct alignas(64) DeResolved
-{
-    uint32_t count;
-    uint32_t total;  // draws thrown away in the whole half-step
-    uint32_t pad[14];
-    DePlan plan[kDeMaxCand];
-};
-
-struct DeCand
-{
-    uint32_t k;
-    uint8_t extra[kDeMaxShift + 1];  // draws thrown away by an update of walker k that starts r draws late
-};
-static_assert(sizeof(DeCand) == 4 * (1 + (kDeMaxShift + 1) / 4), "the planner stages DeCand word by word");
 
 // The stream part of one update, made one half-step ahead (DifferentialEvolution.h:83-87,100)
 template <class T>
@@ -124,108 +118,97 @@ struct DeArgs
     const T* calc_params;
     DeCtl* ctl;             // [4] ring
     DeShared* shared;
-    DeCand* cand;           // [2][kDeMaxCand]: candidates of half-step h live in buffer h & 1
-    DeResolved* resolved;   // [2]: the same resolved
+    DeBad* bad;             // [2][bad_capacity]: bad positions of half-step h live in buffer h & 1
     DeRec<T>* recs;         // [2][n]: records of colour c in buffer c
     const DeRunInfo* run;
     DeStepCtl* step_ctl;    // [2]
     Affine128 half_jump;    // (D+3)*n draws
     const Affine128* jump_hi;     // [ceil(n/256)]  (D+3)*256*m draws
     const Affine128* jump_lo;     // [256]          (D+3)*j draws
-    const Affine128* jump_small;  // [D + kDeRaw + 1]  j draws
+    const Affine128* jump_small;  // [max(D, kDeMaxShift) + 2]  j draws
+    const Affine128* scan_hi;     // [ceil(scan lanes / 256)]  kDeScanRun*256*m draws
+    const Affine128* scan_lo;     // [256]                     kDeScanRun*j draws
     Diag* diag;
     uint64_t threshold;     // (2^64 - n) mod n
     U128 inc;               // pcg stream increment
     T gamma, jitter_low, jitter_width, tie_eps;
     int n, dims, vec_ok;
+    int bad_capacity;       // entries of one bad-position list
+    int scan_positions;     // stream positions a half-step can reach: (D+3)*n + kDeMaxShift + 1
     int half_step_mod4;     // half-step h & 3 of the update this launch performs (colour = h & 1, ensemble step parity = (h >> 1) & 1)
     int update_blocks;      // workgroups [0, update_blocks) update half-step h (0: a planning-only launch)
     int record_blocks;      // the next record_blocks workgroups make the records of half-step h + 1 (0: none, priming); the rest
-                            // find the candidates of half-step h + 2
+                            // scan the positions of half-step h + 2 (priming without records: of half-step h + 1, unresolved)
 };
 
 __device__ __forceinline__ uint32_t de_bounded(uint64_t v, int n, bool pow2) { return pow2 ? (uint32_t)(v & (uint64_t)(n - 1)) : (uint32_t)(v % (uint64_t)n); }
 
-// ---- find: candidates of the half-step whose base state is `state`, appended to cand[0..] through *count ----------------
-// Would an update of walker k that starts r draws late (r = 0..kDeMaxShift) throw draws away?  A wavefront takes kDeFindBatch
-// walkers at a time: first one lane per walker jumps to the walker's base state (two table look-ups), then walker after
-// walker lane j makes raw draw j behind it (one more jump), neighbouring lanes compare, and for the rare walker where the
-// answer is yes for some r, lane r walks the update that starts at draw r and the table extra[r] goes to the candidate list.
-constexpr int kDeFindBatch = 16;
+// ---- scan: every stream position of the half-step whose base state is `state`, drawn once; the bad ones listed ----------
 template <class T>
-__device__ __forceinline__ void de_find(const DeArgs<T>& a, U128 state, DeCand* cand, uint32_t* count, uint64_t (*sh_raw)[64], U128 (*sh_base)[kDeFindBatch],
-                                        int first_batch, int batches_stride)
+__device__ __forceinline__ void de_scan(const DeArgs<T>& a, U128 state, DeBad* bad, uint32_t* count, int first_lane, int lanes_stride)
 {
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int n = a.n;
     const bool pow2 = (n & (n - 1)) == 0;
     const uint64_t threshold = a.threshold;
-    const Affine128 j_draw = a.jump_small[(lane < kDeRaw ? lane : kDeRaw - 1) + 1];
-    for (int k0 = (first_batch + wib) * kDeFindBatch; k0 < n; k0 += batches_stride * kDeFindBatch)
+    const int positions = a.scan_positions;
+    for (int t = first_lane + (int)threadIdx.x; t * kDeScanRun < positions; t += lanes_stride)
     {
-        if (lane < kDeFindBatch)
+        // the state behind kDeScanRun * t draws, then position after position
+        U128 s = apply(a.scan_lo[t & 255], apply(a.scan_hi[t >> 8], state));
+        s = pcg_step(s, a.inc);
+        uint64_t raw = pcg_output(s);
+#pragma unroll 1
+        for (int i = 0; i < kDeScanRun; ++i)
         {
-            const int k = k0 + lane < n ? k0 + lane : n - 1;
-            sh_base[wib][lane] = apply(a.jump_lo[k & 255], apply(a.jump_hi[k >> 8], state));
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int batch = n - k0 < kDeFindBatch ? n - k0 : kDeFindBatch;
-        for (int g = 0; g < batch; ++g)
-        {
-            const int k = k0 + g;
-            const uint64_t raw = pcg_output(apply(j_draw, sh_base[wib][g]));
-            const uint64_t nxt = __shfl_down(raw, 1);
-            // clean(j): draws j and j+1 are both kept and name different walkers: an update starting at j throws nothing away
-            const bool bad = lane <= kDeMaxShift && (raw < threshold || nxt < threshold || de_bounded(raw, n, pow2) == de_bounded(nxt, n, pow2));
-            if (__ballot(bad) == 0) continue;
-            uint32_t slot = 0;
-            if (lane == 0) slot = atomicAdd(count, 1u);
-            slot = __shfl(slot, 0);
-            if (slot >= (uint32_t)kDeMaxCand)
+            const int p = t * kDeScanRun + i;
+            const U128 s_next = pcg_step(s, a.inc);
+            const uint64_t nxt = pcg_output(s_next);
+            // bad: a draw below the threshold, or both draws naming the same walker -- an update starting here throws draws away
+            const bool is_bad = p < positions && (raw < threshold || nxt < threshold || de_bounded(raw, n, pow2) == de_bounded(nxt, n, pow2));
+            if (is_bad)
             {
-                if (lane == 0) atomicOr(&a.shared->error, kDeErrCand);
-                continue;
-            }
-            // (one wavefront: its LDS accesses execute in order; the fences keep the compiler from moving them)
-            sh_raw[wib][lane] = raw;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane <= kDeMaxShift)
-            {
-                // DifferentialEvolution.h:83-87 from draw `lane` on
-                const uint64_t* rw = sh_raw[wib];
-                int at = lane;
-                const int end = lane + kDeWindow;
-                uint64_t v;
-                do v = rw[at++];
-                while (v < threshold && at < end);
-                const uint32_t ind1 = de_bounded(v, n, pow2);
-                uint32_t ind2 = ind1;
-                bool overrun = v < threshold;
-                do
+                // DifferentialEvolution.h:83-87 from this position on (rare: about D + 3 positions of a half-step)
+                U128 w = s;
+                uint64_t v = raw;
+                int used = 1;
+                while (v < threshold && used < kDeWindow)
                 {
-                    if (at >= end)
+                    w = pcg_step(w, a.inc);
+                    v = pcg_output(w);
+                    ++used;
+                }
+                const uint32_t ind1 = de_bounded(v, n, pow2);
+                bool overrun = v < threshold;
+                uint32_t ind2 = ind1;
+                while (!overrun && ind2 == ind1)
+                {
+                    do
                     {
-                        overrun = true;
-                        break;
-                    }
-                    do v = rw[at++];
-                    while (v < threshold && at < end);
-                    if (v < threshold) overrun = true;
-                    ind2 = de_bounded(v, n, pow2);
-                } while (ind2 == ind1);
-                // (an overrun is an error only if the walk over the candidates comes through this start)
-                cand[slot].extra[lane] = overrun ? (uint8_t)kDeOverrun : (uint8_t)(at - lane - 2);
+                        if (used >= kDeWindow)
+                        {
+                            overrun = true;
+                            break;
+                        }
+                        w = pcg_step(w, a.inc);
+                        v = pcg_output(w);
+                        ++used;
+                    } while (v < threshold);
+                    if (!overrun) ind2 = de_bounded(v, n, pow2);
+                }
+                const uint32_t slot = atomicAdd(count, 1u);
+                if (slot < (uint32_t)a.bad_capacity)
+                {
+                    DeBad b;
+                    b.p = (uint32_t)p;
+                    b.e = overrun ? (uint32_t)kDeOverrun : (uint32_t)(used - 2);
+                    bad[slot] = b;
+                }
+                else
+                    atomicOr(&a.shared->error, kDeErrCand);
             }
-            if (lane == 0) cand[slot].k = (uint32_t)k;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            s = s_next;
+            raw = nxt;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -243,29 +226,126 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
     if ((int)blockIdx.x >= a.update_blocks)
     {
         // =================================== planning workgroups ==========================================================
-        __shared__ DePlan sh_plan[kDeMaxCand];
-        __shared__ __attribute__((aligned(16))) DeCand sh_cand[kDeMaxCand];  // as the finders left them
-        __shared__ DeCand sh_sorted[kDeMaxCand];                             // in walker order: the walk never leaves LDS
-        __shared__ uint64_t sh_raw[kWavesPerBlock][64];
-        __shared__ U128 sh_base[kWavesPerBlock][kDeFindBatch];
-        __shared__ int sh_last;
+        __shared__ DePlan sh_plan[kDeMaxEvents];
+        __shared__ DeBad sh_rel[kDeMaxEvents];     // the bad positions that can be a walker's start, as found
+        __shared__ DeBad sh_sorted[kDeMaxEvents];  // by position
+        __shared__ int sh_rel_count, sh_events, sh_total;
         const int pb = (int)blockIdx.x - a.update_blocks;  // planner index
         const int planners = (int)gridDim.x - a.update_blocks;
-        const int h1 = (h4 + 1) & 3, h2 = (h4 + 2) & 3, h3 = (h4 + 3) & 3;
+        const int h1 = (h4 + 1) & 3, h2 = (h4 + 2) & 3;
+        const unsigned per = (unsigned)dims + 3u;
+        const DeCtl ctl1 = a.ctl[h1];
+        if (a.record_blocks == 0)
+        {
+            // priming: nothing to resolve yet -- the positions of half-step h + 1, straight from its record in the ring
+            de_scan<T>(a, ctl1.state, a.bad + (size_t)(h1 & 1) * a.bad_capacity, &a.shared->bad_count[h1], pb * kThreads, planners * kThreads);
+            return;
+        }
+        // ---- resolve half-step h + 1 from its bad positions (listed one launch ago) ----
+        const DeBad* bad1 = a.bad + (size_t)(h1 & 1) * a.bad_capacity;
+        const uint32_t listed = a.shared->bad_count[h1];
+        const int bad_count = (int)(listed < (uint32_t)a.bad_capacity ? listed : (uint32_t)a.bad_capacity);
+        if (threadIdx.x == 0) sh_rel_count = 0;
+        __syncthreads();
+        for (int j = threadIdx.x; j < bad_count; j += kThreads)
+        {
+            const DeBad b = bad1[j];
+            // walker k starts at per * k + r with r <= kDeMaxShift: a position whose residue mod per is larger cannot be a start
+            if (b.p % per <= (unsigned)kDeMaxShift)
+            {
+                const int slot = atomicAdd(&sh_rel_count, 1);
+                if (slot < kDeMaxEvents) sh_rel[slot] = b;
+            }
+        }
+        __syncthreads();
+        int rel = sh_rel_count;
+        uint32_t err = 0;
+        if (rel > kDeMaxEvents)
+        {
+            err |= kDeErrCand;
+            rel = kDeMaxEvents;
+        }
+        for (int j = threadIdx.x; j < rel; j += kThreads)
+        {
+            int rank = 0;
+            const uint32_t mine = sh_rel[j].p;
+            for (int i = 0; i < rel; ++i) rank += sh_rel[i].p < mine ? 1 : 0;  // (positions are distinct)
+            sh_sorted[rank] = sh_rel[j];
+        }
+        __syncthreads();
+        if (wib == 0)
+        {
+            // The walk, in stream order: with r draws thrown away so far, walker k starts at per * k + r; the next event is
+            // the first listed position that IS the start of a walker behind the last event's.  One ballot per event;
+            // lane l holds entries l and l + 64.
+            static_assert(kDeMaxEvents == 128, "two entries per lane");
+            const DeBad e0 = lane < rel ? sh_sorted[lane] : DeBad{0u, 0u};
+            const DeBad e1 = lane + 64 < rel ? sh_sorted[lane + 64] : DeBad{0u, 0u};
+            int r = 0, events = 0, last_k = -1;  // (a position inside the draws of the walker whose start was the last event is no start)
+            while (true)
+            {
+                // is this entry the start of a walker k in (last_k, n) when r draws have been thrown away?
+                auto starts = [&](const DeBad& e, bool have) -> bool {
+                    if (!have || e.p < (uint32_t)r) return false;
+                    const uint32_t d = e.p - (uint32_t)r;
+                    const uint32_t q = d / per;
+                    return d - q * per == 0u && (int)q > last_k && (int)q < n;
+                };
+                const unsigned long long m0 = __ballot(starts(e0, lane < rel));
+                const unsigned long long m1 = __ballot(starts(e1, lane + 64 < rel));
+                int at;
+                if (m0)
+                    at = __ffsll((long long)m0) - 1;
+                else if (m1)
+                    at = 64 + __ffsll((long long)m1) - 1;
+                else
+                    break;
+                const uint32_t ep = at < 64 ? __shfl(e0.p, at) : __shfl(e1.p, at - 64);
+                uint32_t own = at < 64 ? __shfl(e0.e, at) : __shfl(e1.e, at - 64);
+                if (own == (uint32_t)kDeOverrun)
+                {
+                    err |= kDeErrWindow;
+                    own = 0;
+                }
+                const int ek = (int)((ep - (uint32_t)r) / per);  // (r: still the shift this walker starts with)
+                r += (int)own;
+                if (r > kDeMaxShift)
+                {
+                    err |= kDeErrShift;
+                    r = kDeMaxShift;
+                }
+                if (lane == 0)
+                {
+                    sh_plan[events].k = (uint32_t)ek;
+                    sh_plan[events].shift_after = (uint32_t)r;
+                }
+                ++events;
+                last_k = ek;
+            }
+            if (lane == 0)
+            {
+                sh_events = events;
+                sh_total = r;
+                if (pb == 0)
+                {
+                    // hand the stream on: the record of half-step h + 2 (its last reader was the launch before this one),
+                    // and clear the bad-position counter of half-step h + 3 (scanned by the next launch)
+                    DeCtl* nx = a.ctl + h2;
+                    nx->state = apply(a.jump_small[r], apply(a.half_jump, ctl1.state));
+                    nx->extra_total = ctl1.extra_total + (unsigned long long)r;
+                    a.shared->bad_count[(h4 + 3) & 3] = 0;
+                    if (err) atomicOr(&a.shared->error, err);
+                }
+            }
+        }
+        __syncthreads();
         if (pb < a.record_blocks)
         {
-            // ---- records of half-step h + 1: its candidates were found and resolved one launch ago ----
-            const DeCtl* ctl1 = a.ctl + h1;
-            const DeResolved* res = a.resolved + (h1 & 1);
-            const U128 state1 = ctl1->state;
-            const int plan_count = (int)res->count;
-            for (int j = threadIdx.x; j < plan_count; j += kThreads) sh_plan[j] = res->plan[j];
+            // ---- records of half-step h + 1: one lane per walker ----
             const int k = pb * kThreads + (int)threadIdx.x;
-            const int kc = k < n ? k : n - 1;
-            const Affine128 j_hi = a.jump_hi[kc >> 8], j_lo = a.jump_lo[kc & 255], j_exp = a.jump_small[dims];
-            __syncthreads();
             if (k >= n) return;
-            // this walker's place in the stream: the last list entry in front of it says how late it starts
+            const int plan_count = sh_events;
+            // this walker's place in the stream: the last event in front of it says how late it starts
             int lo = 0, hi = plan_count;  // first entry with k' >= k
             while (lo < hi)
             {
@@ -276,7 +356,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
                     hi = mid;
             }
             const int shift = lo > 0 ? (int)sh_plan[lo - 1].shift_after : 0;
-            U128 s = apply(a.jump_small[shift], apply(j_lo, apply(j_hi, state1)));
+            U128 s = apply(a.jump_small[shift], apply(a.jump_lo[k & 255], apply(a.jump_hi[k >> 8], ctl1.state)));
             // ind1, ind2 (DifferentialEvolution.h:83-87), thrown-away draws included; the plan bounds the loops
             const bool pow2 = (n & (n - 1)) == 0;
             uint64_t v;
@@ -298,7 +378,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
                 ind2 = de_bounded(v, n, pow2);
             } while (ind2 == ind1 && --budget > 0);
             // the exponential (draw D behind the integer draws and the D jitters): MultiSampler.h:80
-            const U128 se = pcg_step(apply(j_exp, s), a.inc);
+            const U128 se = pcg_step(apply(a.jump_small[dims], s), a.inc);
             DeRec<T>* out = a.recs + (size_t)(h1 & 1) * n + k;
             out->s = s;
             out->neg_exp = dev_log((T)1 - canonical(pcg_output(se), T()));  // -(-log(1 - u)/1)
@@ -306,82 +386,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
             out->ind2 = ind2;
             return;
         }
-        // ---- candidates of half-step h + 2 (its base state was left in the ring by the launch before this one) ----
-        const int fb = pb - a.record_blocks, finders = planners - a.record_blocks;
-        const DeCtl ctl2 = a.ctl[h2];
-        DeCand* cand2 = a.cand + (size_t)(h2 & 1) * kDeMaxCand;
-        de_find<T>(a, ctl2.state, cand2, &a.shared->cand_count[h2], sh_raw, sh_base, fb * kWavesPerBlock, finders * kWavesPerBlock);
-        // The finder workgroup that finishes last resolves the list: sorted by walker, then walked in order, each candidate
-        // starting as late as those before it made it (r += extra[r], the only sequential part: a few dozen steps from
-        // LDS), and hands the stream on.  Hand-off: every storing wavefront drains its stores, workgroup barrier, agent
-        // release, ticket; the last arriver acquires before it reads.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t ticket = __hip_atomic_fetch_add(&a.shared->finished[h2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh_last = ticket + 1u == (uint32_t)finders ? 1 : 0;
-            if (sh_last)
-            {
-                __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        }
-        __syncthreads();
-        if (!sh_last) return;
-        const uint32_t count2 = __hip_atomic_load(&a.shared->cand_count[h2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int plan_count = (int)(count2 < (uint32_t)kDeMaxCand ? count2 : (uint32_t)kDeMaxCand);
-        for (int t = (int)threadIdx.x; t < plan_count * 9; t += kThreads)  // (a DeCand is nine words)
-            reinterpret_cast<uint32_t*>(sh_cand)[t] = reinterpret_cast<const uint32_t*>(cand2)[t];
-        __syncthreads();
-        for (int j = threadIdx.x; j < plan_count; j += kThreads)
-        {
-            int rank = 0;
-            const uint32_t mine = sh_cand[j].k;
-            for (int i = 0; i < plan_count; ++i) rank += sh_cand[i].k < mine ? 1 : 0;  // (walker indices are distinct)
-            sh_sorted[rank] = sh_cand[j];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            int r = 0;
-            uint32_t err = 0;
-            for (int j = 0; j < plan_count; ++j)
-            {
-                int own = (int)sh_sorted[j].extra[r];
-                if (own == kDeOverrun)
-                {
-                    err |= kDeErrWindow;
-                    own = 0;
-                }
-                r += own;
-                if (r > kDeMaxShift)
-                {
-                    err |= kDeErrShift;
-                    r = kDeMaxShift;
-                }
-                sh_plan[j].k = sh_sorted[j].k;
-                sh_plan[j].shift_after = (uint32_t)r;
-            }
-            DeResolved* res = a.resolved + (h2 & 1);
-            res->count = (uint32_t)plan_count;
-            res->total = (uint32_t)r;
-            // the record of half-step h + 3 (its last reader was two launches ago)
-            DeCtl* nx = a.ctl + h3;
-            nx->state = apply(a.jump_small[r], apply(a.half_jump, ctl2.state));
-            nx->extra_total = ctl2.extra_total + (unsigned long long)r;
-            // this half-step's counters are free for the half-step four later
-            a.shared->cand_count[h2] = 0;
-            a.shared->finished[h2] = 0;
-            if (err) atomicOr(&a.shared->error, err);
-        }
-        __syncthreads();
-        {
-            DeResolved* res = a.resolved + (h2 & 1);
-            for (int j = threadIdx.x; j < plan_count; j += kThreads) res->plan[j] = sh_plan[j];
-        }
+        // ---- the positions of half-step h + 2: its base state follows from the resolve ----
+        const U128 state2 = apply(a.jump_small[sh_total], apply(a.half_jump, ctl1.state));
+        const int scanners = planners - a.record_blocks;
+        de_scan<T>(a, state2, a.bad + (size_t)(h2 & 1) * a.bad_capacity, &a.shared->bad_count[h2], (pb - a.record_blocks) * kThreads, scanners * kThreads);
         return;
     }
 
