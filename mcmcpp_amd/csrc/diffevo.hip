@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -77,8 +78,10 @@ public:
         HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * 2 * (size_t)bad_capacity));
         HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * 2 * (size_t)bad_capacity));
         HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * (size_t)n));
-        HIP_TRY(hipMalloc(&d_run, sizeof(DeRunInfo)));
-        HIP_TRY(hipMalloc(&d_step, sizeof(DeStepCtl) * 2));
+        // the two per-step records and, right behind them, the run's constants: one allocation (the kernel reads both
+        // through one preloaded pointer)
+        HIP_TRY(hipMalloc(&d_step, sizeof(DeStepCtl) * 2 + sizeof(DeRunInfo)));
+        d_run = reinterpret_cast<DeRunInfo*>(d_step + 2);
         HIP_TRY(hipMemset(d_shared, 0, sizeof(DeShared)));
         for (int k = 0; k < 2; ++k)
         {
@@ -91,6 +94,9 @@ public:
             const char* v = std::getenv("MCMCPP_HIP_DE_FIND_WALKERS");
             knob_walkers_per_find_wave = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 1;
             if (knob_walkers_per_find_wave < 1) knob_walkers_per_find_wave = 1;
+            v = std::getenv("MCMCPP_HIP_DE_SCAN_RUN");  // stream positions one scanning lane steps through
+            scan_run = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeScanRun;
+            if (scan_run < 1) scan_run = 1;
             v = std::getenv("MCMCPP_HIP_DE_DEBUG");
             knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
         }
@@ -117,7 +123,7 @@ public:
         const unsigned per = (unsigned)D + 3u;
         {
             scan_positions = (int)per * n + kDeMaxShift + 1;
-            const size_t scan_lanes = ((size_t)scan_positions + kDeScanRun - 1) / kDeScanRun;
+            const size_t scan_lanes = ((size_t)scan_positions + scan_run - 1) / scan_run;
             std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256), small((size_t)(D > kDeMaxShift ? D : kDeMaxShift) + 2);
             std::vector<Affine128> slo(256), shi((scan_lanes + 255) / 256);
             Affine128 id;
@@ -128,7 +134,7 @@ public:
             for (size_t j = 1; j < lo.size(); ++j) lo[j] = compose(step_u, lo[j - 1]);
             for (size_t m = 1; m < hi.size(); ++m) hi[m] = compose(step_b, hi[m - 1]);
             for (size_t j = 1; j < small.size(); ++j) small[j] = compose(step_1, small[j - 1]);
-            const Affine128 step_r = pcg_jump(inc, kDeScanRun), step_rb = pcg_jump(inc, (unsigned __int128)kDeScanRun * 256u);
+            const Affine128 step_r = pcg_jump(inc, (unsigned)scan_run), step_rb = pcg_jump(inc, (unsigned __int128)scan_run * 256u);
             slo[0] = shi[0] = id;
             for (size_t j = 1; j < slo.size(); ++j) slo[j] = compose(step_r, slo[j - 1]);
             for (size_t m = 1; m < shi.size(); ++m) shi[m] = compose(step_rb, shi[m - 1]);
@@ -246,6 +252,7 @@ public:
         a.bad = d_bad;
         a.bad_capacity = bad_capacity;
         a.scan_positions = scan_positions;
+        a.scan_run = scan_run;
         a.scan_hi = d_scan_hi;
         a.scan_lo = d_scan_lo;
         a.recs = d_recs;
@@ -265,12 +272,14 @@ public:
         a.n = n;
         a.dims = D;
         a.vec_ok = vec_ok;
+        if (knob_debug == 3 && !d_debug) HIP_TRY(hipMalloc(&d_debug, sizeof(unsigned long long) * 2 * 8192));
+        a.debug_times = d_debug;
         const int per_block = (64 / lpw) * kWavesPerBlock;
         update_blocks = (n + per_block - 1) / per_block;
         record_blocks = (n + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
         // scanners: a lane per kDeScanRun stream positions (knob: that many runs per lane)
         {
-            const long lanes = ((long)scan_positions + kDeScanRun - 1) / kDeScanRun;
+            const long lanes = ((long)scan_positions + scan_run - 1) / scan_run;
             const long per_wg = 64L * kWavesPerBlock * knob_walkers_per_find_wave;
             find_blocks = (int)((lanes + per_wg - 1) / per_wg);
             if (find_blocks < 1) find_blocks = 1;
@@ -328,6 +337,27 @@ public:
                 }
         }
         steps_since_reset += (uint64_t)total;
+        if (d_debug)
+        {
+            // diagnostics: when the workgroups of the LAST launch started and ended, by role (us from the first start)
+            const int grid = update_blocks + record_blocks + find_blocks;
+            std::vector<unsigned long long> t((size_t)2 * grid);
+            HIP_TRY(hipMemcpy(t.data(), d_debug, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ULL;
+            for (int b = 0; b < grid; ++b) t0 = t[2 * b] < t0 ? t[2 * b] : t0;
+            const char* names[3] = {"records", "scan", "update"};
+            const int lo[3] = {0, record_blocks, record_blocks + find_blocks}, hi[3] = {record_blocks, record_blocks + find_blocks, grid};
+            for (int r = 0; r < 3; ++r)
+            {
+                double s0 = 1e9, s1 = 0, e0 = 1e9, e1 = 0;
+                for (int b = lo[r]; b < hi[r]; ++b)
+                {
+                    const double st = (t[2 * b] - t0) * 0.01, en = (t[2 * b + 1] - t0) * 0.01;
+                    s0 = st < s0 ? st : s0, s1 = st > s1 ? st : s1, e0 = en < e0 ? en : e0, e1 = en > e1 ? en : e1;
+                }
+                std::fprintf(stderr, "[de debug] %-8s %4d workgroups: start %.2f..%.2f us, end %.2f..%.2f us\n", names[r], hi[r] - lo[r], s0, s1, e0, e1);
+            }
+        }
         DeShared sh;
         HIP_TRY(hipMemcpy(&sh, d_shared, sizeof sh, hipMemcpyDeviceToHost));
         last_ms = gpu_ms;  // GPU time of the step launches between HIP events on the launch stream (transfers excluded)
@@ -517,7 +547,7 @@ private:
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
         for (hipGraphExec_t ex : graph_cache)
             if (ex) (void)hipGraphExecDestroy(ex);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_run, d_step, d_bad, d_scan_lo, d_scan_hi};
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_step, d_bad, d_scan_lo, d_scan_hi, d_debug};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         for (int k = 0; k < 2; ++k)
@@ -540,8 +570,9 @@ private:
     DeCtl* d_ctl = nullptr;
     DeShared* d_shared = nullptr;
     DeBad* d_bad = nullptr;
+    unsigned long long* d_debug = nullptr;
     Affine128 *d_scan_lo = nullptr, *d_scan_hi = nullptr;
-    int bad_capacity = 0, scan_positions = 0;
+    int bad_capacity = 0, scan_positions = 0, scan_run = kDeScanRun;
     DeRec<T>* d_recs = nullptr;
     DeRunInfo* d_run = nullptr;
     DeStepCtl* d_step = nullptr;

@@ -41,7 +41,7 @@ constexpr int kDeWindow = 32;     // raw draws one update's integer part may con
                                   // walkers per half, where every second ind2 collides, overrun once in 1e9 updates)
 constexpr int kDeOverrun = 255;   // E of a start whose update would not fit that window
 constexpr int kDeMaxEvents = 128; // bad positions that can be a walker's start, per half-step (typical: about 32)
-constexpr int kDeScanRun = 8;     // consecutive stream positions one scanning lane steps through
+constexpr int kDeScanRun = 2;     // consecutive stream positions one scanning lane steps through (default of DeArgs::scan_run)
 constexpr int kDeAccSlots = 64;   // counters an ensemble step's accepted proposals are spread over (same-address atomics serialise)
 
 enum : uint32_t
@@ -126,8 +126,8 @@ struct DeArgs
     const Affine128* jump_hi;     // [ceil(n/256)]  (D+3)*256*m draws
     const Affine128* jump_lo;     // [256]          (D+3)*j draws
     const Affine128* jump_small;  // [max(D, kDeMaxShift) + 2]  j draws
-    const Affine128* scan_hi;     // [ceil(scan lanes / 256)]  kDeScanRun*256*m draws
-    const Affine128* scan_lo;     // [256]                     kDeScanRun*j draws
+    const Affine128* scan_hi;     // [ceil(scan lanes / 256)]  scan_run*256*m draws
+    const Affine128* scan_lo;     // [256]                     scan_run*j draws
     Diag* diag;
     uint64_t threshold;     // (2^64 - n) mod n
     U128 inc;               // pcg stream increment
@@ -135,8 +135,10 @@ struct DeArgs
     int n, dims, vec_ok;
     int bad_capacity;       // entries of one bad-position list
     int scan_positions;     // stream positions a half-step can reach: (D+3)*n + kDeMaxShift + 1
+    int scan_run;           // consecutive positions one scanning lane steps through (the scan tables are built for it)
     int half_step_mod4;     // half-step h & 3 of the update this launch performs (colour = h & 1, ensemble step parity = (h >> 1) & 1)
     int update_blocks;      // workgroups [0, update_blocks) update half-step h (0: a planning-only launch)
+    unsigned long long* debug_times;  // diagnostics (MCMCPP_HIP_DE_DEBUG=3): [grid][2] start / end of every workgroup, 100 MHz clock
     int record_blocks;      // the next record_blocks workgroups make the records of half-step h + 1 (0: none, priming); the rest
                             // scan the positions of half-step h + 2 (priming without records: of half-step h + 1, unresolved)
 };
@@ -150,17 +152,17 @@ __device__ __forceinline__ void de_scan(const DeArgs<T>& a, U128 state, DeBad* b
     const int n = a.n;
     const bool pow2 = (n & (n - 1)) == 0;
     const uint64_t threshold = a.threshold;
-    const int positions = a.scan_positions;
-    for (int t = first_lane + (int)threadIdx.x; t * kDeScanRun < positions; t += lanes_stride)
+    const int positions = a.scan_positions, run = a.scan_run;
+    for (int t = first_lane + (int)threadIdx.x; t * run < positions; t += lanes_stride)
     {
-        // the state behind kDeScanRun * t draws, then position after position
+        // the state behind run * t draws, then position after position
         U128 s = apply(a.scan_lo[t & 255], apply(a.scan_hi[t >> 8], state));
         s = pcg_step(s, a.inc);
         uint64_t raw = pcg_output(s);
 #pragma unroll 1
-        for (int i = 0; i < kDeScanRun; ++i)
+        for (int i = 0; i < run; ++i)
         {
-            const int p = t * kDeScanRun + i;
+            const int p = t * run + i;
             const U128 s_next = pcg_step(s, a.inc);
             const uint64_t nxt = pcg_output(s_next);
             // bad: a draw below the threshold, or both draws naming the same walker -- an update starting here throws draws away
@@ -212,26 +214,47 @@ __device__ __forceinline__ void de_scan(const DeArgs<T>& a, U128 state, DeBad* b
     }
 }
 
+// hot_bits of de_step_kernel: dims | half_step_mod4 << 12 | vec_ok << 14
+__host__ __device__ inline uint32_t de_hot_bits(int dims, int half_step_mod4, int vec_ok) { return (uint32_t)dims | ((uint32_t)half_step_mod4 << 12) | ((uint32_t)vec_ok << 14); }
+
+// The hot_* arguments are what an updating wavefront needs before its second round trip; they travel in the 16 dwords
+// the command processor preloads into SGPRs (see HotBits in stretch_kernel.hpp), everything else in `a`, whose cold
+// kernarg lines an updating wavefront touches only behind its second trip's loads.
 template <class T, class Calc, int EPL, int LPW>
-__global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeArgs<T> a)
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+de_step_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>* hot_recs, const Affine128* hot_jump_small, DeStepCtl* hot_step_ctl, int hot_n,
+               uint32_t hot_bits, int hot_planner_blocks, const DeArgs<T> a)
 {
     constexpr int WPP = 64 / LPW;
     constexpr int kThreads = 64 * kWavesPerBlock;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int dims = a.dims, n = a.n;
+    const int dims = (int)(hot_bits & 0xFFFu), n = hot_n;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int h4 = a.half_step_mod4;
+    const int h4 = (int)((hot_bits >> 12) & 3u);
 
-    if ((int)blockIdx.x >= a.update_blocks)
+    struct StampWorkgroup  // (diagnostics: nothing unless a buffer is given)
+    {
+        unsigned long long* slot;
+        __device__ StampWorkgroup(unsigned long long* base) : slot(base ? base + 2 * (size_t)blockIdx.x : nullptr)
+        {
+            if (slot && threadIdx.x == 0) slot[0] = __builtin_amdgcn_s_memrealtime();
+        }
+        __device__ ~StampWorkgroup()
+        {
+            if (slot && threadIdx.x == 0) slot[1] = __builtin_amdgcn_s_memrealtime();
+        }
+    } stamp(a.debug_times);
+    // (the planners come first in the grid: theirs is the longer dependent chain)
+    if ((int)blockIdx.x < hot_planner_blocks)
     {
         // =================================== planning workgroups ==========================================================
         __shared__ DePlan sh_plan[kDeMaxEvents];
         __shared__ DeBad sh_rel[kDeMaxEvents];     // the bad positions that can be a walker's start, as found
         __shared__ DeBad sh_sorted[kDeMaxEvents];  // by position
         __shared__ int sh_rel_count, sh_events, sh_total;
-        const int pb = (int)blockIdx.x - a.update_blocks;  // planner index
-        const int planners = (int)gridDim.x - a.update_blocks;
+        const int pb = (int)blockIdx.x;  // planner index
+        const int planners = hot_planner_blocks;
         const int h1 = (h4 + 1) & 3, h2 = (h4 + 2) & 3;
         const unsigned per = (unsigned)dims + 3u;
         const DeCtl ctl1 = a.ctl[h1];
@@ -396,38 +419,42 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
     // ======================================= update workgroups: half-step h ===============================================
     T* sh_stage = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::stage_offset());
     T* sh_block = reinterpret_cast<T*>(smem + LdsLayout<T, Calc, EPL>::block_offset());
-    const bool vec_ok = a.vec_ok != 0;
+    const bool vec_ok = ((hot_bits >> 14) & 1u) != 0;
     const bool has_block_scratch = Calc::block_scratch_elems(dims) != 0;
-    typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
     const int color = h4 & 1;
     const int sub = lane & (LPW - 1);
-    const int k = (blockIdx.x * kWavesPerBlock + wib) * WPP + lane / LPW;  // walker inside the half
+    const int ub = (int)blockIdx.x - hot_planner_blocks;                    // updating workgroup
+    const int k = (ub * kWavesPerBlock + wib) * WPP + lane / LPW;           // walker inside the half
     const bool active = k < n;
     const int kk = active ? k : 0;
     const int half_base = color ? n : 0, other_base = color ? 0 : n;
     const int w = half_base + kk;
     const int i0 = sub * EPL;
 
-    // first round trip: what the walker index alone addresses
-    const DeRec<T> rec = a.recs[(size_t)color * n + kk];
+    // first round trip, from preloaded arguments only: what the walker index alone addresses
+    const DeRec<T> rec = hot_recs[(size_t)color * n + kk];
     T own[EPL];
-    load_slice<T, EPL>(a.pos + (size_t)w * dims, i0, dims, vec_ok, active, own);
-    const T lp_old = a.logp[w];
-    const uint32_t nacc_old = a.n_accept[w];
-    const Affine128 j_uni = a.jump_small[i0 < dims ? i0 : dims];
+    load_slice<T, EPL>(hot_pos + (size_t)w * dims, i0, dims, vec_ok, active, own);
+    const T lp_old = hot_logp[w];
+    const uint32_t nacc_old = hot_n_accept[w];
+    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 : dims];
+    // the per-step counters and, right behind the two records of them, the run's constants (one allocation: DeStepCtl[2],
+    // DeRunInfo), through a preloaded pointer: one more load of the first round trip instead of a round trip of its own
     // (field by field: a whole-record copy drags the padding through registers and scratch)
-    const DeStepCtl* scp = a.step_ctl + ((h4 >> 1) & 1);
+    const DeStepCtl* scp = hot_step_ctl + ((h4 >> 1) & 1);
+    const DeRunInfo* rip = reinterpret_cast<const DeRunInfo*>(hot_step_ctl + 2);
     const long long sc_step = scp->step_in_piece, sc_slot = scp->chain_slot;
     const uint32_t sc_phase = scp->save_phase;
-    void* const run_chain = a.run->chain;
-    uint32_t* const run_accepted = a.run->accepted;
-    const long long run_interval = a.run->interval;
+    void* const run_chain = rip->chain;
+    uint32_t* const run_accepted = rip->accepted;
+    const long long run_interval = rip->interval;
 
     // second round trip: the two partner rows
     T w1[EPL], w2[EPL];
-    load_slice<T, EPL>(a.pos + (size_t)(other_base + (int)rec.ind1) * dims, i0, dims, vec_ok, active, w1);
-    load_slice<T, EPL>(a.pos + (size_t)(other_base + (int)rec.ind2) * dims, i0, dims, vec_ok, active, w2);
+    load_slice<T, EPL>(hot_pos + (size_t)(other_base + (int)rec.ind1) * dims, i0, dims, vec_ok, active, w1);
+    load_slice<T, EPL>(hot_pos + (size_t)(other_base + (int)rec.ind2) * dims, i0, dims, vec_ok, active, w2);
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
 
     Calc::block_commit(calc_pf, sh_block, a.calc_params, dims, vec_ok, (int)threadIdx.x, kThreads);
     if (has_block_scratch) __syncthreads();
@@ -443,9 +470,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
 
     // the ensemble step ends with the black half: one lane of the grid advances the per-step counters
     const bool saved_step = sc_phase + 1u == (uint32_t)run_interval;
-    if (color == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+    if (color == 1 && ub == 0 && threadIdx.x == 0)
     {
-        DeStepCtl* nx = a.step_ctl + (((h4 >> 1) + 1) & 1);
+        DeStepCtl* nx = hot_step_ctl + (((h4 >> 1) + 1) & 1);
         nx->step_in_piece = sc_step + 1;
         nx->save_phase = saved_step ? 0u : sc_phase + 1u;
         nx->chain_slot = sc_slot + (saved_step ? 1 : 0);
@@ -485,11 +512,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
     }
     if (accept)
     {
-        store_slice<T, EPL>(a.pos + (size_t)w * dims, i0, dims, vec_ok, prop);
+        store_slice<T, EPL>(hot_pos + (size_t)w * dims, i0, dims, vec_ok, prop);
         if (sub == 0)
         {
-            a.logp[w] = lp_new;
-            a.n_accept[w] = nacc_old + 1u;
+            hot_logp[w] = lp_new;
+            hot_n_accept[w] = nacc_old + 1u;
         }
     }
     if (save_slot >= 0 && active)
@@ -502,7 +529,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) de_step_kernel(const DeAr
     }
     const unsigned acc = (unsigned)__popcll(__ballot(accept && sub == 0));
     if (run_accepted != nullptr && lane == 0 && acc != 0)
-        atomicAdd(run_accepted + (size_t)sc_step * kDeAccSlots + ((blockIdx.x * kWavesPerBlock + wib) & (kDeAccSlots - 1)), acc);
+        atomicAdd(run_accepted + (size_t)sc_step * kDeAccSlots + ((ub * kWavesPerBlock + wib) & (kDeAccSlots - 1)), acc);
 }
 
 }  // namespace mcmcpp

@@ -71,7 +71,8 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_de(const DeArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    hipLaunchKernelGGL((de_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a);
+    hipLaunchKernelGGL((de_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.pos, a.logp, a.n_accept, a.recs, a.jump_small, a.step_ctl,
+                       a.n, de_hot_bits(a.dims, a.half_step_mod4, a.vec_ok), (int)grid - a.update_blocks, a);
 }
 
 template <class T, class Calc, int LPWLOG, int EPLSHIFT>
