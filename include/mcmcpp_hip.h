@@ -109,8 +109,8 @@ typedef struct mcmcpp_hip_config {
      * ensemble of num_walkers walkers of its own, seeded with seed + k on the same stream.  0 or 1: one ensemble.  With
      * K = num_chains > 1 every array argument gains a leading chain dimension: set_state positions[K][W][D], logp[K][W];
      * run chain_out[K][n_saved][W][D] (chain k's stored steps are contiguous, like that sampler's own Chain),
-     * accepted_per_step[K][steps]; get_state likewise.  Counters are summed over the chains.  Needs ensembles small
-     * enough to be stepped with one launch per ensemble step (W <= 32768), whole on one device; at most 16 chains. */
+     * accepted_per_step[K][steps]; get_state likewise.  Counters are summed over the chains.  Whole ensembles on one
+     * device (no shards, no communicator); at most 16 chains. */
     int32_t num_chains;
     int32_t reserved0;
 } mcmcpp_hip_config;

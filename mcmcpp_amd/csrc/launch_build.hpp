@@ -13,12 +13,14 @@ template <class T, class Calc, int EPL, int LPW>
 void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr);
+    const int chains = a.chains > 1 ? a.chains : 1;
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
+                          ((uint32_t)(chains - 1) << 28);
     if (a.draw_wave)
-        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos, a.logp,
+        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos, a.logp,
                            a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
     else
-        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos, a.logp,
+        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, false>), dim3(grid, chains), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos, a.logp,
                            a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 
@@ -26,12 +28,14 @@ template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
-    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr);
+    const int chains = a.chains > 1 ? a.chains : 1;
+    const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
+                          ((uint32_t)(chains - 1) << 28);
     if (a.draw_wave)
-        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, true>), dim3(grid), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos,
+        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos,
                            a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
     else
-        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, false>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos,
+        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, false>), dim3(grid, chains), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos,
                            a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
 }
 

@@ -291,6 +291,12 @@ public:
         // served by the draw wavefront) and 16 for the largest ensembles.  Measured, 32 dims fp64 (tools/sweep_passes.txt):
         // 65 536 walkers 5.2 / 5.8 / 4.4e9 walker-steps/s with 4 / 8 / 16 walkers per wavefront, 262 144: 7.4e9 with 8,
         // 1 M: 6.7 / 8.0 / 7.8 / 7.4e9 with 8 / 16 / 32 / 64.
+        // Independent ensembles stepped by the same launches (BASELINE config 4 on one GPU): chain k is seeded with
+        // seed + k on the same stream, so all chains share the jump tables; see ChainGeometry for the layout.  What a
+        // launch has to fill the chip with is the walkers of all chains together.
+        K = c.num_chains > 1 ? c.num_chains : 1;
+        if (K > kMaxChains) return fail(MCMCPP_HIP_E_ARG, "num_chains %d exceeds %d", K, kMaxChains);
+        const long launch_walkers = (long)shard_count * K;  // walkers of one colour a launch updates
         const int wpp = 64 / lpw;
         long forced = knobs.passes;
         if (forced > 0)
@@ -298,9 +304,9 @@ public:
         else
         {
             const long target_waves = (long)num_cus * 4 * knobs.waves_per_simd;
-            const int per_wave_cap = shard_count > 196608 ? 16 : 8;
+            const int per_wave_cap = launch_walkers > 196608 ? 16 : 8;
             passes = 1;
-            while (passes * 2 <= lpw && wpp * passes * 2 <= per_wave_cap && (long)shard_count / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
+            while (passes * 2 <= lpw && wpp * passes * 2 <= per_wave_cap && launch_walkers / ((long)wpp * passes * 2) >= target_waves) passes *= 2;
         }
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;
@@ -309,7 +315,7 @@ public:
         const long mc_min = knobs.matrix_core_min_walkers;
         if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
         {
-            const int big = shard_count >= knobs.matrix_core_4pass ? 1 : 0;
+            const int big = launch_walkers >= knobs.matrix_core_4pass ? 1 : 0;
             half_fn = table->half_step_mc[big][lpw_log][epl_shift];
             passes = big ? 4 : 2;
         }
@@ -321,7 +327,7 @@ public:
         full_fn = nullptr;
         const bool whole = shard_count == n && shard_begin == 0;
         if ((whole ? knobs.full_step != 0 : (c.comm_world >= 1 && knobs.comm_full_step != 0 && knobs.full_step != 0)) &&
-            2 * (long)shard_count <= knobs.full_step_max_walkers)
+            2 * launch_walkers <= knobs.full_step_max_walkers)
         {
             full_fn = table->full_step[lpw_log][epl_shift];
             full_wpb = kWavesPerBlock * (64 / lpw);
@@ -333,15 +339,8 @@ public:
             }
         }
 
-        // Independent ensembles stepped by the same launches (BASELINE config 4 on one GPU): chain k is seeded with
-        // seed + k on the same stream, so all chains share the jump tables; see ChainGeometry for the layout.
-        K = c.num_chains > 1 ? c.num_chains : 1;
-        if (K > 1)
-        {
-            if (K > kMaxChains) return fail(MCMCPP_HIP_E_ARG, "num_chains %d exceeds %d", K, kMaxChains);
-            if (!full_fn) return fail(MCMCPP_HIP_E_UNSUPPORTED, "num_chains > 1 needs ensembles of at most %ld walkers (one launch per ensemble step)", knobs.full_step_max_walkers);
-            if (!whole || c.comm_world >= 1 || c.device_positions) return fail(MCMCPP_HIP_E_ARG, "num_chains > 1: whole ensembles on one device only (no shards, communicator or caller-owned positions)");
-        }
+        if (K > 1 && (!whole || c.comm_world >= 1 || c.device_positions))
+            return fail(MCMCPP_HIP_E_ARG, "num_chains > 1: whole ensembles on one device only (no shards, communicator or caller-owned positions)");
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
         {
             stream = (hipStream_t)c.hip_stream;  // may be the null (legacy default) stream
@@ -423,7 +422,7 @@ public:
         HIP_TRY(hipMemset(d_ctl, 0, (size_t)kCtlChainStride * (size_t)K));
         // pinned scratch of the host: [0, 512) as before (control record at 128, four run records from 256 on);
         // per-chain control records from 1024, per-chain run records from 1024 + 64 * kMaxChains on
-        HIP_TRY(hipHostMalloc(&h_pinned, 1024 + 128 * kMaxChains, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&h_pinned, 1024 + 64 * kMaxChains + 4 * 64 * kMaxChains, hipHostMallocDefault));
 
         // calculator parameters (the dense Gaussian's matrix goes over transposed: see DenseGaussianFn)
         if (c.calc_params_len > 0)
@@ -544,6 +543,15 @@ public:
         return rc;
     }
 
+    // staging -> the caller's memory: stored steps [first, first + count) of every chain (chain k's steps are n_saved steps
+    // apart in the caller's array, sub_saved steps apart in the staging buffer)
+    void hand_out_subchunk(char* chain_out, const char* stage, size_t step_bytes, int64_t sub_saved, int64_t n_saved, int64_t first, int64_t count) const
+    {
+        for (int k = 0; k < K; ++k)
+            std::memcpy(chain_out + step_bytes * ((size_t)n_saved * (size_t)k + (size_t)first), stage + step_bytes * (size_t)sub_saved * (size_t)k,
+                        step_bytes * (size_t)count);
+    }
+
     // A failure after the first launch of a run leaves walkers, control records and draw records ahead of the host's
     // counters (and possibly the live ensemble in the second buffer, or the stream in capture mode): nothing on the
     // device can be trusted any more.  The handle then insists on a new set_state, as the DE sampler does.
@@ -582,7 +590,7 @@ public:
         int64_t sub_saved = n_saved;  // stored steps per sub-chunk
         if (chain_out)
         {
-            sub_saved = (int64_t)(chain_subchunk_bytes / step_bytes);
+            sub_saved = (int64_t)(chain_subchunk_bytes / (step_bytes * (size_t)K));
             const int64_t eighth = (n_saved + 7) / 8;  // keep the last (un-overlappable) host copy short
             if (sub_saved > eighth) sub_saved = eighth;
             if (sub_saved < 1) sub_saved = 1;
@@ -604,8 +612,7 @@ public:
             if (per_chunk < 1) per_chunk = 1;
             chunk_steps = per_chunk * interval;
         }
-        if (K > 1 && chain_out && !trickle) return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: several chains store steps only through the forwarding path (rows of whole 16-byte pieces)");
-        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total * K : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved : 0,
+        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total * K : 0, (chain_out && !trickle) ? step_bytes * (size_t)sub_saved * K : 0,
                                     trickle ? step_bytes * (size_t)ring * K : 0, direct_stage == nullptr);
         if (rc) return rc;
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total * K, stream));
@@ -644,11 +651,12 @@ public:
             const int64_t now = (n_saved - first < sub_saved) ? n_saved - first : sub_saved;
             for (int k = 0; k < K; ++k)
             {
-                // (several chains: nothing is stored on this path, one record each, uploaded once)
-                RunInfo* ri = K > 1 ? reinterpret_cast<RunInfo*>((char*)h_pinned + 1024 + 64 * kMaxChains + 64 * k)
+                // (several chains: one record each; the upload slots rotate per sub-chunk as for one chain)
+                RunInfo* ri = K > 1 ? reinterpret_cast<RunInfo*>((char*)h_pinned + 1024 + 64 * kMaxChains + 64 * k + 64 * kMaxChains * (c % 4))
                                     : reinterpret_cast<RunInfo*>((char*)h_pinned + 256 + 64 * (c % 4));
                 static_assert(sizeof(RunInfo) <= 64, "the pinned upload slots are 64 bytes apart");
-                ri->chain = chain_out ? d_chain[buf] : nullptr;
+                // chain k's stored steps of this sub-chunk: the k-th run of sub_saved steps of the device half
+                ri->chain = chain_out ? (void*)((char*)d_chain[buf] + step_bytes * (size_t)sub_saved * (size_t)k) : nullptr;
                 ri->accepted_per_step = accepted_per_step ? d_acc + (size_t)k * (size_t)total : nullptr;
                 ri->interval = interval;
                 ri->chain_slot_base = -first;
@@ -673,23 +681,25 @@ public:
             if (chain_out)
             {
                 // the staging buffer is free: its previous content (sub-chunk c-2) was copied out below
+                // (the whole device half in one copy: with several chains, chain k's steps sit sub_saved steps apart)
+                const size_t half_used = K > 1 ? step_bytes * (size_t)sub_saved * (size_t)(K - 1) + step_bytes * (size_t)now : step_bytes * (size_t)now;
                 if (copy_stream)
                 {
                     // the download runs beside the next sub-chunk's launches (which fill the other device half)
                     HIP_TRY(hipEventRecord(ev_filled[buf], stream));
                     HIP_TRY(hipStreamWaitEvent(copy_stream, ev_filled[buf], 0));
-                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], step_bytes * (size_t)now, hipMemcpyDeviceToHost, copy_stream));
+                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], half_used, hipMemcpyDeviceToHost, copy_stream));
                     HIP_TRY(hipEventRecord(ev_copied[buf], copy_stream));
                 }
                 else
                 {
-                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], step_bytes * (size_t)now, hipMemcpyDeviceToHost, stream));
+                    HIP_TRY(hipMemcpyAsync(h_stage[buf], d_chain[buf], half_used, hipMemcpyDeviceToHost, stream));
                     HIP_TRY(hipEventRecord(ev_copied[buf], stream));
                 }
                 if (pending_first >= 0)
                 {
                     HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
-                    std::memcpy((char*)chain_out + step_bytes * (size_t)pending_first, h_stage[pending_buf], step_bytes * (size_t)pending_count);
+                    hand_out_subchunk((char*)chain_out, (const char*)h_stage[pending_buf], step_bytes, sub_saved, n_saved, pending_first, pending_count);
                     publish_stored(pending_first + pending_count);
                 }
                 pending_first = first;
@@ -703,7 +713,7 @@ public:
             if (pending_first >= 0)
             {
                 HIP_TRY(hipEventSynchronize(ev_copied[pending_buf]));
-                std::memcpy((char*)chain_out + step_bytes * (size_t)pending_first, h_stage[pending_buf], step_bytes * (size_t)pending_count);
+                hand_out_subchunk((char*)chain_out, (const char*)h_stage[pending_buf], step_bytes, sub_saved, n_saved, pending_first, pending_count);
                 publish_stored(pending_first + pending_count);
             }
             if (full_fn && (run_step & 1))

@@ -182,7 +182,7 @@ struct alignas(64) HalfStepArgs
     int draw_parity;            // ensemble step & 1: which record buffer this launch reads
     int draw_wave;              // 1: the workgroup carries extra wavefronts that compute the next draws
     int pos_parity;             // full-step kernels: 0: read pos/logp, write pos_alt/logp_alt; 1: the reverse
-    int chains;                 // full-step kernels: independent ensembles stepped by this launch (grid.y), 1..kMaxChains
+    int chains;                 // independent ensembles stepped by this launch (grid.y), 1..kMaxChains
 };
 
 // This lane's EPL elements of a walker row; cells beyond D (and everything when !active) are +0.  Branch-free on
@@ -508,7 +508,7 @@ __device__ __forceinline__ void compute_draw(const HalfStepArgs<T>& a, U128 base
 struct HotBits
 {
     // (bit 26: full-step kernels' position-buffer parity; bit 27: the one-entry-per-draw jump table exists;
-    //  bits 28-31: full-step kernels: chains - 1)
+    //  bits 28-31: chains - 1)
     static __host__ __device__ uint32_t pack(int dims, int passes, int color, int vec_ok, int n_is_pow2, int use_ctl_save,
                                              int draw_parity, int draw_wave, int direct_jump)
     {
@@ -520,7 +520,7 @@ struct HotBits
 
 // Hands the random stream and the step counters to the next half-step launch (one lane of the whole grid).
 template <class T>
-__device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCtl& ctl, const RunInfo& run, int color)
+__device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCtl& ctl, const RunInfo& run, int color, StepCtl* ctl_out)
 {
     StepCtl nx = ctl;
     nx.state = apply(a.half_jump, ctl.state);
@@ -535,7 +535,7 @@ __device__ __forceinline__ void hand_over(const HalfStepArgs<T>& a, const StepCt
         nx.chain_slot = ctl.chain_slot + (saved ? 1 : 0);
         nx.partial_slot = (ctl.partial_slot + 1u == (uint32_t)a.partial_slots) ? 0u : ctl.partial_slot + 1u;
     }
-    *a.ctl_out = nx;
+    *ctl_out = nx;
 }
 
 // Stored steps reach the host without a copy engine and without a gap in the launch sequence: every launch forwards
@@ -686,6 +686,17 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     // `a` is the launch description in the kernarg segment; the h_* locals are the preloaded copies of the
     // fields every wavefront needs before its first memory access (same values, no kernarg fetch)
     const HalfStepArgs<T>& a = rest;
+    // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride; a branch on
+    // purpose -- chain 0, i.e. every single-ensemble launch, skips the 64-bit products
+    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const void* const draws_chain0 = hot_draws;
+    if (__builtin_expect(chain != 0, 0))
+    {
+        hot_draws += (size_t)chain * 4 * (size_t)hot_n;
+        hot_pos += (size_t)chain * 2 * (size_t)hot_n * (size_t)(hot_bits & 0xFFFu);
+        hot_logp = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp) + (size_t)chain * logp_chain_stride_bytes<T>(hot_n));
+        hot_n_accept = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hot_n_accept) + (size_t)chain * logp_chain_stride_bytes<T>(hot_n));
+    }
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
     constexpr bool h_draw_wave = DW;  // (hot_bits bit 25 says the same)
@@ -727,8 +738,9 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         if (wib == kWavesPerBlock)
         {
             // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-            draw_wave_body<T, 2>(a, jump_tables_behind(hot_draws, hot_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0,
-                                 h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane);
+            draw_wave_body<T, 2>(a, jump_tables_behind(draws_chain0, hot_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in, Calc::block_scratch_elems(h_dims) != 0,
+                                 h_draws_next, h_draws_next, 1, h_shard_begin, h_shard_count, blockIdx.x * kWavesPerBlock * nw, kWavesPerBlock * nw, lane, false,
+                                 nullptr, -1, chain);
             return;
         }
     }
@@ -769,8 +781,15 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     typename Calc::Prefetch calc_pf;
     Calc::block_prefetch(calc_pf, a.calc_params, h_dims, vec_ok, (int)threadIdx.x, 64 * kWavesPerBlock);
 
-    const StepCtl ctl = *hot_ctl_in;  // wave-uniform
-    const RunInfo run = *a.run;
+    const StepCtl* ctl_mine = hot_ctl_in;
+    const RunInfo* run_mine = a.run;
+    if (__builtin_expect(chain != 0, 0))  // (the chain's own records, ChainGeometry)
+    {
+        ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_mine) + (size_t)chain * kCtlChainStride);
+        run_mine = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(run_mine) + (size_t)chain * kCtlChainStride);
+    }
+    const StepCtl ctl = *ctl_mine;  // wave-uniform
+    const RunInfo run = *run_mine;
 
     // the draws of the NEXT update of this wavefront's walkers: task t = 3*slot + k is draw k of walker `slot`
     const int tasks = 3 * nw;
@@ -804,7 +823,8 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
 
     // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
     // in the extra wavefront it would lengthen the last wavefront to finish: measured)
-    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over<T>(a, ctl, run, h_color);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        hand_over<T>(a, ctl, run, h_color, reinterpret_cast<StepCtl*>(reinterpret_cast<char*>(a.ctl_out) + (size_t)chain * kCtlChainStride));
     if (!wave_active) return;
 
     // does this ensemble step go to the chain?  (EnsembleSampler.h:298-306: interval-1 unsaved, 1 saved)
@@ -935,7 +955,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     // per-wavefront accepted count of this half-step; summed per ensemble step by accepted_reduce_kernel
     // (one plain store per wavefront: thousands of same-address atomics would serialise for ~12 ns each)
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
-        a.partials[((size_t)ctl.partial_slot * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
+        a.partials[(((size_t)chain * (size_t)a.partial_slots + (size_t)ctl.partial_slot) * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
 }
 
 // Fills the draw records of one colour for the half-step whose base engine state is `base` (one thread per
@@ -1046,6 +1066,16 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
 #endif
     MCMCPP_STAMP(0);
     MCMCPP_STAMP_BLOCK(0);
+    // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry), as in the kernel above
+    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const void* const draws_chain0 = hot_draws;
+    if (__builtin_expect(chain != 0, 0))
+    {
+        hot_draws += (size_t)chain * 4 * (size_t)hot_n;
+        hot_pos += (size_t)chain * 2 * (size_t)hot_n * (size_t)(hot_bits & 0xFFFu);
+        hot_logp = reinterpret_cast<T*>(reinterpret_cast<char*>(hot_logp) + (size_t)chain * logp_chain_stride_bytes<T>(hot_n));
+        hot_n_accept = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(hot_n_accept) + (size_t)chain * logp_chain_stride_bytes<T>(hot_n));
+    }
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
     constexpr bool h_draw_wave = DW;
@@ -1066,9 +1096,9 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         if ((threadIdx.x >> 6) == kWavesPerBlock)
         {
             // the workgroup's extra wavefront: next draws of every walker this workgroup updates
-            draw_wave_body<T, 2>(a, jump_tables_behind(hot_draws, hot_n, ((hot_bits >> 27) & 1u) != 0), hot_ctl_in,
+            draw_wave_body<T, 2>(a, jump_tables_behind(draws_chain0, hot_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in,
                                  true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
-                                 h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane);
+                                 h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane, false, nullptr, -1, chain);
             return;
         }
     }
@@ -1109,8 +1139,15 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     typename Calc::Prefetch calc_pf;
     Calc::block_prefetch(calc_pf, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);  // updating wavefronts only
 
-    const StepCtl ctl = *hot_ctl_in;
-    const RunInfo run = *a.run;
+    const StepCtl* ctl_mine = hot_ctl_in;
+    const RunInfo* run_mine = a.run;
+    if (__builtin_expect(chain != 0, 0))  // (the chain's own records, ChainGeometry)
+    {
+        ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_mine) + (size_t)chain * kCtlChainStride);
+        run_mine = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(run_mine) + (size_t)chain * kCtlChainStride);
+    }
+    const StepCtl ctl = *ctl_mine;
+    const RunInfo run = *run_mine;
     const int slot_a = lane / 3, k_a = lane - 3 * slot_a;  // 3*NW lanes compute the walkers' next draws
     const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
     const bool direct_jump = a.task_jump != nullptr;
@@ -1140,7 +1177,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     __syncthreads();
     // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
     // in the extra wavefront it would lengthen the last wavefront to finish: measured)
-    if (blockIdx.x == 0 && threadIdx.x == 0) hand_over<T>(a, ctl, run, h_color);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        hand_over<T>(a, ctl, run, h_color, reinterpret_cast<StepCtl*>(reinterpret_cast<char*>(a.ctl_out) + (size_t)chain * kCtlChainStride));
     if (!wave_active) return;
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
@@ -1215,7 +1253,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     }
 #endif
     if (a.partials != nullptr && run.accepted_per_step != nullptr && lane == 0)
-        a.partials[((size_t)ctl.partial_slot * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
+        a.partials[(((size_t)chain * (size_t)a.partial_slots + (size_t)ctl.partial_slot) * 2 + (size_t)h_color) * (size_t)a.partial_waves + (size_t)wave] = accepted_here;
 }
 
 // Before the first full-step launch of a run(): no row of the second position buffer can be trusted (set_state and

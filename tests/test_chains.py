@@ -22,7 +22,9 @@ def _oracles(K, W, D, calc, params, seed):
 
 
 @pytest.mark.parametrize("K,W,D,calc", [(3, 4096, 32, po.CALC_DENSE_GAUSSIAN), (2, 2048, 16, po.CALC_ISO_GAUSSIAN), (5, 1024, 7, po.CALC_ROSENBROCK),
-                                        (16, 512, 32, po.CALC_DENSE_GAUSSIAN)])
+                                        (16, 512, 32, po.CALC_DENSE_GAUSSIAN),
+                                        # together more than 32 768 walkers: stepped by the half-step kernels (matrix-core and plain)
+                                        (5, 8192, 32, po.CALC_DENSE_GAUSSIAN), (3, 16384, 8, po.CALC_ISO_GAUSSIAN), (2, 32768, 16, po.CALC_ROSENBROCK)])
 @pytest.mark.parametrize("pinned", [False, True])
 def test_chains_stepped_together_equal_chains_stepped_alone(K, W, D, calc, pinned):
     rng = np.random.default_rng(5)
@@ -68,8 +70,6 @@ def test_chains_stepped_together_equal_chains_stepped_alone(K, W, D, calc, pinne
 def test_chains_config_is_checked():
     with pytest.raises(capi.HipError):  # too many
         capi.HipSampler(512, 8, po.CALC_ISO_GAUSSIAN, None, num_chains=17)
-    with pytest.raises(capi.HipError):  # ensembles stepped by the half-step kernels are not batched
-        capi.HipSampler(65536, 8, po.CALC_ISO_GAUSSIAN, None, num_chains=2)
     with pytest.raises(capi.HipError):  # one mover only
         capi.HipSampler(512, 8, po.CALC_ISO_GAUSSIAN, None, num_chains=2, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
     h = capi.HipSampler(512, 8, po.CALC_ISO_GAUSSIAN, None, num_chains=2)
