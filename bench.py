@@ -218,7 +218,9 @@ def bench_split(args, rank, local_rank, world, dist, torch, capi):
         kernel = ("stretch_full_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>" if per_step_launches < 1.5 else
                   "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>")
         step_us = gpu_ms * 1e3 / n_steps  # GPU time of one ensemble step on the launch stream: kernels + exchange
-        kern_us = max(step_us - xchg, 1e-9) / per_step_launches
+        # per launch, between several ranks without the sampled exchange time; a single rank's "exchange" moves nothing and
+        # its events only bracket launch gaps, so there the whole stream time is charged to the launches
+        kern_us = (max(step_us - xchg, 1e-9) if world > 1 else step_us) / per_step_launches
         bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
         achieved = updates * bytes_per_update / (kern_us * 1e-6) / 1e9
         line = {
@@ -235,7 +237,8 @@ def bench_split(args, rank, local_rank, world, dist, torch, capi):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates,
                          "algorithmic_bytes_per_launch": updates * bytes_per_update, "avg_launch_us": kern_us,
-                         "note": "per rank; launch time = (stream time of a step - sampled exchange time) / launches per step"},
+                         "note": "per rank; launch time = (stream time of a step - sampled exchange time) / launches per step; with one "
+                                 "rank the exchange calls are charged to the launches"},
             "allgather": {"bytes_received_per_rank_per_step": recv, "exchange_us_per_step": xchg,
                           "gb_per_s_per_rank": (recv / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,
                           "gb_per_s_per_link": (recv / (world - 1) / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,

@@ -326,7 +326,7 @@ public:
         // so the ranks exchange rows once per ensemble step), by the size of what it updates.
         full_fn = nullptr;
         const bool whole = shard_count == n && shard_begin == 0;
-        if ((whole ? knobs.full_step != 0 : (c.comm_world >= 1 && knobs.comm_full_step != 0 && knobs.full_step != 0)) &&
+        if ((c.comm_world >= 1 ? (knobs.comm_full_step != 0 && knobs.full_step != 0) : (whole && knobs.full_step != 0)) &&
             2 * launch_walkers <= knobs.full_step_max_walkers)
         {
             full_fn = table->full_step[lpw_log][epl_shift];
@@ -878,7 +878,7 @@ public:
         };
 
         const int64_t sample_stride = total > kMaxSamples ? total / kMaxSamples : 1;
-        int samples = 0;
+        int samples = 0, unreduced = 0;
         int64_t staged = 0, handed = 0;  // stored steps copied to staging / handed to the caller
         auto drain_stage = [&]() -> int {
             HIP_TRY(hipStreamSynchronize(stream));
@@ -903,7 +903,12 @@ public:
                     slice(args_red, r);
                     enqueue_step(parity, pos_parity);
                 }
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                // (the per-wavefront accepted counts are summed once per partial_slots steps, and at the end of the run)
+                if (++unreduced == partial_slots || s + 1 == total)
+                {
+                    launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                    unreduced = 0;
+                }
                 HIP_TRY(hipGetLastError());
                 cur_pos = pos_parity ? d_pos : d_pos_alt;
                 T* cur_logp = pos_parity ? d_logp : d_logp + W;
@@ -932,7 +937,11 @@ public:
                     slice(args_blk, r);
                     half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
                 }
-                launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                if (++unreduced == partial_slots || s + 1 == total)
+                {
+                    launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                    unreduced = 0;
+                }
                 HIP_TRY(hipGetLastError());
                 rc = exchange_rows(d_pos, nullptr, 1, 1);
                 if (rc) return rc;
