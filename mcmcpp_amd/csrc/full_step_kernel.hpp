@@ -82,7 +82,7 @@ __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, co
 // first control record.
 // (kRunBehindCtlBytes, stretch_kernel.hpp)
 
-template <class T, class Calc, int EPL, int LPW>
+template <class T, class Calc, int EPL, int LPW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
 stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const RunInfo* hot_run, int hot_sh_begin, int hot_sh_count, int hot_n,
                          uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
@@ -91,9 +91,9 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
     constexpr int WPP = 64 / LPW;  // walkers of each colour per wavefront
     const int h_n = hot_n;
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
-    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const int chain = MC ? (int)blockIdx.y : 0, chains = MC ? (int)(hot_bits >> 28) + 1 : 1;  // (MC: see stretch_half_step_kernel)
     const void* const draws_chain0 = hot_draws;
-    if (__builtin_expect(chain != 0, 0))  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
+    if (MC && chain != 0)  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
     {
         hot_draws += (size_t)chain * 4 * (size_t)h_n;
         hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)(hot_bits & 0xFFFu);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void store_row_piece(double* p, double x0, double x1)
     store_through16(p, v);
 }
 
-template <class T, class Calc, int EPL, int LPW>
+template <class T, class Calc, int EPL, int LPW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
 stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, int hot_sh_begin, int hot_sh_count, int hot_n,
                               uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
@@ -364,9 +364,9 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     const int h_n = hot_n;
     const int h_dims = (int)(hot_bits & 0xFFFu);
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride
-    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+    const int chain = MC ? (int)blockIdx.y : 0, chains = MC ? (int)(hot_bits >> 28) + 1 : 1;  // (MC: see stretch_half_step_kernel)
     const void* const draws_chain0 = hot_draws;
-    if (__builtin_expect(chain != 0, 0))  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
+    if (MC && chain != 0)  // (a branch on purpose: chain 0 -- every single-ensemble launch -- skips the 64-bit products)
     {
         hot_draws += (size_t)chain * 4 * (size_t)h_n;
         hot_pos_a += (size_t)chain * 2 * (size_t)h_n * (size_t)h_dims;

@@ -16,12 +16,19 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);
-    if (a.draw_wave)
-        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos, a.logp,
-                           a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+#define MCMCPP_LAUNCH_HALF(DW, MC, THREADS)                                                                                                              \
+    hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, DW, MC>), dim3(grid, chains), dim3(THREADS), lds, st, a.draws, a.pos, a.logp, a.n_accept, a.n, \
+                       bits, a.shard_begin, a.shard_count, a.ctl_in, a)
+    // (four instantiations: with / without the draw wavefront, for one ensemble / several chains per launch)
+    if (a.draw_wave && chains > 1)
+        MCMCPP_LAUNCH_HALF(true, true, 64 * (kWavesPerBlock + 1));
+    else if (a.draw_wave)
+        MCMCPP_LAUNCH_HALF(true, false, 64 * (kWavesPerBlock + 1));
+    else if (chains > 1)
+        MCMCPP_LAUNCH_HALF(false, true, 64 * kWavesPerBlock);
     else
-        hipLaunchKernelGGL((stretch_half_step_kernel<T, Calc, EPL, LPW, false>), dim3(grid, chains), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos, a.logp,
-                           a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+        MCMCPP_LAUNCH_HALF(false, false, 64 * kWavesPerBlock);
+#undef MCMCPP_LAUNCH_HALF
 }
 
 template <class T, class Calc, int EPL, int LPW, int P>
@@ -31,12 +38,18 @@ void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);
-    if (a.draw_wave)
-        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + 1)), lds, st, a.draws, a.pos,
-                           a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+#define MCMCPP_LAUNCH_HALF_MC(DW, MC, THREADS)                                                                                                            \
+    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, DW, MC>), dim3(grid, chains), dim3(THREADS), lds, st, a.draws, a.pos, a.logp, a.n_accept, \
+                       a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a)
+    if (a.draw_wave && chains > 1)
+        MCMCPP_LAUNCH_HALF_MC(true, true, 64 * (kWavesPerBlock + 1));
+    else if (a.draw_wave)
+        MCMCPP_LAUNCH_HALF_MC(true, false, 64 * (kWavesPerBlock + 1));
+    else if (chains > 1)
+        MCMCPP_LAUNCH_HALF_MC(false, true, 64 * kWavesPerBlock);
     else
-        hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, false>), dim3(grid, chains), dim3(64 * kWavesPerBlock), lds, st, a.draws, a.pos,
-                           a.logp, a.n_accept, a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a);
+        MCMCPP_LAUNCH_HALF_MC(false, false, 64 * kWavesPerBlock);
+#undef MCMCPP_LAUNCH_HALF_MC
 }
 
 template <class T, class Calc, int EPL, int LPW>
@@ -46,8 +59,12 @@ void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 1, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr), a.pos_parity) |
                           ((uint32_t)(chains - 1) << 28);
-    hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
-                       st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
+    if (chains > 1)
+        hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))),
+                           lds, st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
+    else
+        hipLaunchKernelGGL((stretch_full_step_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * (kWavesPerBlock + (a.draw_wave ? kFullDrawWaves : 0))), lds,
+                           st, a.draws, a.pos, a.pos_alt, a.logp, a.run, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>
@@ -59,8 +76,12 @@ void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
                           ((uint32_t)(chains - 1) << 28);
     // (logp_alt == logp + W, n_accept == logp + 2 W and the run record kRunBehindCtlBytes behind the control records: the
     //  kernel derives them and takes the padded matrix and the shard bounds as preloaded arguments instead)
-    hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
-                       a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
+    if (chains > 1 || a.chains < 0)  // (a.chains < 0: experiments -- the several-chains instantiation for one ensemble)
+        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+                           a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
+    else
+        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+                           a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 
 template <class T, class Calc, int EPL, int LPW>

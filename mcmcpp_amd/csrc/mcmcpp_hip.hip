@@ -93,6 +93,7 @@ struct Knobs
     long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
+    long force_multi_chain_kernels; // MCMCPP_HIP_FORCE_MC                experiments: single ensembles stepped by the several-chains instantiations (0)
     long comm_emulate_ranks;      // MCMCPP_HIP_COMM_EMULATE_RANKS       diagnostic, single-rank communicators only: step the ensemble as G slices,
                                   //                                     one launch each, as G ranks would (tests the sliced kernels on one GPU) (1)
     static Knobs from_environment()
@@ -114,6 +115,7 @@ struct Knobs
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
         k.comm_emulate_ranks = env_long("MCMCPP_HIP_COMM_EMULATE_RANKS", 1);
+        k.force_multi_chain_kernels = env_long("MCMCPP_HIP_FORCE_MC", 0);
         return k;
     }
 };
@@ -1381,7 +1383,7 @@ private:
         a.logp_alt = d_logp + W;
         a.pos_parity = 0;
         a.calc_params_padded = d_params_padded;
-        a.chains = K;
+        a.chains = (K == 1 && knobs.force_multi_chain_kernels != 0) ? -1 : K;
         // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
         a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && knobs.no_draw_wave == 0) ? 1 : 0;
         return a;

@@ -678,7 +678,7 @@ __device__ __forceinline__ void draw_wave_body(const HalfStepArgs<T>& a, const J
 // draw wavefront's code raises the kernel's register count (85 against 64 VGPRs for the isotropic target), which
 // costs the variant without it -- the one large, bandwidth-bound ensembles take -- occupancy (measured at 1 M
 // walkers: 73.7 against 68.8 us per launch).
-template <class T, class Calc, int EPL, int LPW, bool DW>
+template <class T, class Calc, int EPL, int LPW, bool DW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                          int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
@@ -688,9 +688,11 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     const HalfStepArgs<T>& a = rest;
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry): every per-chain array at its fixed stride; a branch on
     // purpose -- chain 0, i.e. every single-ensemble launch, skips the 64-bit products
-    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+        // (MC: built for several chains per launch; the single-ensemble instantiation carries none of it -- measured 2 % of a
+    //  65 536-walker launch otherwise)
+    const int chain = MC ? (int)blockIdx.y : 0, chains = MC ? (int)(hot_bits >> 28) + 1 : 1;
     const void* const draws_chain0 = hot_draws;
-    if (__builtin_expect(chain != 0, 0))
+    if (MC && chain != 0)
     {
         hot_draws += (size_t)chain * 4 * (size_t)hot_n;
         hot_pos += (size_t)chain * 2 * (size_t)hot_n * (size_t)(hot_bits & 0xFFFu);
@@ -783,7 +785,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
 
     const StepCtl* ctl_mine = hot_ctl_in;
     const RunInfo* run_mine = a.run;
-    if (__builtin_expect(chain != 0, 0))  // (the chain's own records, ChainGeometry)
+    if (MC && chain != 0)  // (the chain's own records, ChainGeometry)
     {
         ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_mine) + (size_t)chain * kCtlChainStride);
         run_mine = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(run_mine) + (size_t)chain * kCtlChainStride);
@@ -1045,7 +1047,7 @@ __device__ __forceinline__ void mc_eval(const McB& B, double* sx, int sub, int g
 }
 
 // P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
-template <class T, class Calc, int EPL, int LPW, int P, bool DW>
+template <class T, class Calc, int EPL, int LPW, int P, bool DW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
@@ -1067,9 +1069,11 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     MCMCPP_STAMP(0);
     MCMCPP_STAMP_BLOCK(0);
     // chain blockIdx.y of (hot_bits >> 28) + 1 (ChainGeometry), as in the kernel above
-    const int chain = (int)blockIdx.y, chains = (int)(hot_bits >> 28) + 1;
+        // (MC: built for several chains per launch; the single-ensemble instantiation carries none of it -- measured 2 % of a
+    //  65 536-walker launch otherwise)
+    const int chain = MC ? (int)blockIdx.y : 0, chains = MC ? (int)(hot_bits >> 28) + 1 : 1;
     const void* const draws_chain0 = hot_draws;
-    if (__builtin_expect(chain != 0, 0))
+    if (MC && chain != 0)
     {
         hot_draws += (size_t)chain * 4 * (size_t)hot_n;
         hot_pos += (size_t)chain * 2 * (size_t)hot_n * (size_t)(hot_bits & 0xFFFu);
@@ -1141,7 +1145,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
 
     const StepCtl* ctl_mine = hot_ctl_in;
     const RunInfo* run_mine = a.run;
-    if (__builtin_expect(chain != 0, 0))  // (the chain's own records, ChainGeometry)
+    if (MC && chain != 0)  // (the chain's own records, ChainGeometry)
     {
         ctl_mine = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_mine) + (size_t)chain * kCtlChainStride);
         run_mine = reinterpret_cast<const RunInfo*>(reinterpret_cast<const char*>(run_mine) + (size_t)chain * kCtlChainStride);
