@@ -271,7 +271,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-ensemble secondary measurements")
     ap.add_argument("--no-chain", action="store_true", help="experiments only: store nothing")
-    ap.add_argument("--pageable-chain", action="store_true", help="experiments only: stored steps into pageable host memory")
+    ap.add_argument("--pinned-chain", action="store_true",
+                    help="stored steps into a pinned block from the library (MCMCPP_CHAIN_MEMORY=pinned in the facade): the launches "
+                         "write them in place, no staging ring, no host copy")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
     ap.add_argument("--mode", default="chains", choices=["chains", "split"],
                     help="chains (default, the headline): one independent C2 chain per GPU; split: BASELINE config 5, "
@@ -326,16 +328,17 @@ def main():
     pos = workloads.init_positions(W, D, salt=rank)
     sampler.set_state(pos, sampler.calc_logp(pos))
 
-    # The stored steps land in host memory that already exists, like a block of the facade's Chain: pinned host memory
-    # handed out by the library (include/MCMCpp/Device/SamplerCore.h allocates its blocks the same way), so the step
-    # launches forward stored steps straight into it.  The transfer is inside the timed region either way.
+    # The stored steps land in host memory that already exists, like a block of the facade's Chain
+    # (include/MCMCpp/Device/SamplerCore.h): by default heap memory, as the facade's default -- the launches forward stored
+    # steps to a pinned staging ring and the host copies them out while the launches continue; with --pinned-chain a pinned
+    # block from the library, which the launches write in place.  The transfer is inside the timed region either way.
     if args.no_chain:
         chain_block = None
-    elif args.pageable_chain:
-        chain_block = np.zeros((n_saved, W, D))
-    else:
+    elif args.pinned_chain:
         chain_block = capi.pinned_empty((n_saved, W, D))
         chain_block[:] = 0.0
+    else:
+        chain_block = np.zeros((n_saved, W, D))
 
     def bench_step():
         return sampler.run(n_saved, interval=args.interval, save_chain=not args.no_chain,
@@ -407,7 +410,7 @@ def main():
                                                        else "one chain"),
                        "walkers": W, "dims": D, "ensemble_steps_per_step": args.batch,
                        "slicing_interval": args.interval, "chains": world,
-                       "chain_memory": "none" if args.no_chain else ("pageable" if args.pageable_chain else "pinned block from the library")},
+                       "chain_memory": "none" if args.no_chain else ("pinned block from the library" if args.pinned_chain else "heap block (pageable)")},
             "roofline": roof,
         }
         if args.calc != "dense":

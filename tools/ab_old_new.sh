@@ -3,6 +3,6 @@
 cd "$GRAFT_REPO_ROOT"
 for k in 1 2 3; do
   (cd ab_old && python bench.py --steps 40 --warmup 3 --no-cpu-baseline) | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('old', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
-  python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary --pageable-chain | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new pageable', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
-  python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new pinned', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
+  python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new pageable', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
+  python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary --pinned-chain | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('new pinned', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'])"
 done
