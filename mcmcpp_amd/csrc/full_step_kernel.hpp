@@ -396,6 +396,8 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
                                sh_count, kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0, chain);
         return;
     }
+    // the updating wavefronts go ahead of the draw wavefronts they share SIMDs with (5.646 -> 5.626 us per launch at C2)
+    __builtin_amdgcn_s_setprio(3);
     const int wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const int first = wave * NW;  // (relative to the shard)
     if (first >= sh_count) return;  // (no workgroup barrier in this kernel)

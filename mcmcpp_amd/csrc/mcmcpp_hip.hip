@@ -1065,7 +1065,11 @@ public:
         };
         while (enq < total)
         {
-            const int64_t now = (total - enq < chunk_steps) ? total - enq : chunk_steps;
+            int64_t now = (total - enq < chunk_steps) ? total - enq : chunk_steps;
+            // The stored steps that become complete with the LAST chunk are copied out with nothing left to overlap: the
+            // run ends with a chunk of one interval, so that this tail is one stored step instead of a chunk's worth
+            // (11.80 -> 11.55 ms per 2 000 steps at C2)
+            if (!direct && now == total - enq && now > (int64_t)interval) now -= interval;
             // at most two chunks in flight, and no launch may forward into a ring slot that is still to be copied out
             // (forwarding into the final place needs no such care: a device slot is reused ring + 1 stored steps after it
             //  was written, its forwarding is over one stored step after)

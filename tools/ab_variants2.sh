@@ -1,8 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-for k in 1 2; do
-  (cd ab_old && python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-chain) | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('old', d['value'], d['roofline']['avg_launch_us'])"
-  for lib in "" "mcmcpp_amd/libmcmcpp_hip_noshard.so" "mcmcpp_amd/libmcmcpp_hip_oldtrickle.so"; do
+for k in 1 2 3; do
+  for lib in "" "mcmcpp_amd/libmcmcpp_hip_prio3.so"; do
     MCMCPP_HIP_LIB=$lib python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-secondary --no-chain | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('lib=[$lib]', d['value'], d['roofline']['avg_launch_us'])"
   done
 done
