@@ -1,8 +1,9 @@
 // diffevo.hip -- host side of Mover::DifferentialEvolution on gfx950 (reference
 // MCMCpp/Movers/DifferentialEvolution.h:80-112 inside EnsembleSampler::performStep, EnsembleSampler.h:342-354).
-// See diffevo_kernel.hpp for the scheme: ONE launch per half-step (update of half-step h beside the stream planning of
-// h + 1 and h + 2), replayed from a hipGraph; the stream position, the error flags and the per-run counters travel in
-// device memory.
+// See diffevo_kernel.hpp for the scheme: the random stream is planned a batch of half-steps at a time (scan, resolve,
+// records) on a second HIP stream beside the update launches of the batch before, one update launch per half-step; a
+// run is replayed from hipGraphs whose edges are the event waits between the two streams; the stream head, the error
+// flags and the per-run counters travel in device memory.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -14,6 +15,7 @@
 #include <new>
 #include <vector>
 
+#include "diffevo_plan.hpp"
 #include "launch_table.hpp"
 #include "sampler_base.hpp"
 
@@ -67,41 +69,69 @@ public:
             own_stream = true;
         }
 
+        HIP_TRY(hipStreamCreateWithFlags(&plan_stream, hipStreamNonBlocking));
+        {
+            const char* v = std::getenv("MCMCPP_HIP_DE_SCAN_RUN");  // stream positions one scanning lane steps through
+            scan_run = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeScanRun;
+            if (scan_run < 1) scan_run = 1;
+            v = std::getenv("MCMCPP_HIP_DE_BATCH");  // half-steps planned by one batch of planning launches
+            batch_max = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeBatchMax;
+            v = std::getenv("MCMCPP_HIP_DE_DEBUG");  // timing diagnostics (the chain is wrong): 1 = the update launches alone, 2 = the planning alone
+            knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
+            v = std::getenv("MCMCPP_HIP_DE_OVERLAP");  // 0: planning in the launch stream, in front of the updates it plans
+            knob_overlap = (v && *v) ? (int)std::strtol(v, nullptr, 10) != 0 : true;
+        }
+        // the batch: as many half-steps as the position counters (32 bits), the resolver's lists and a sensible amount of
+        // record memory (128 MiB) allow
+        const unsigned per = (unsigned)D + 3u;
+        {
+            long long b = batch_max < 1 ? 1 : (batch_max > kDeBatchMax ? kDeBatchMax : batch_max);
+            const long long by_positions = ((1LL << 30) - kDeShiftMax - 1) / ((long long)per * n);
+            const long long by_lists = (kDeMaxBad * 5LL / 8) / per;
+            const long long by_records = (4LL << 20) / n;
+            b = b < by_positions ? b : by_positions;
+            b = b < by_lists ? b : by_lists;
+            b = b < by_records ? b : by_records;
+            if (by_positions < 1) return fail(MCMCPP_HIP_E_UNSUPPORTED, "differential evolution: %d walkers x %d parameters exceed the planner's 2^30 stream positions per half-step", W, D);
+            batch_max = b < 1 ? 1 : (int)b;
+        }
+        const size_t updates_max = (size_t)batch_max * n;
+        positions_max = (long long)per * (long long)(updates_max - 1) + kDeShiftMax + 1;
+        // a batch lists about (D + 3) bad positions per half-step (one position in n is bad), spread evenly over the lists
+        bad_capacity = 4 * (int)((per * (unsigned)batch_max + kDeSegments - 1) / kDeSegments) + 64;
+
         HIP_TRY(hipMalloc(&d_pos, sizeof(T) * (size_t)W * D));
         HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
         HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
-        HIP_TRY(hipMalloc(&d_ctl, sizeof(DeCtl) * 4));
-        HIP_TRY(hipMalloc(&d_shared, sizeof(DeShared)));
-        // a half-step has about D + 3 bad positions (one per walker collides with probability 1/n, (D+3)n positions)
-        bad_capacity = 8 * (D + 3) + 512;
-        HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * 2 * (size_t)bad_capacity));
-        HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * 2 * (size_t)bad_capacity));
-        HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * (size_t)n));
-        // the two per-step records and, right behind them, the run's constants: one allocation (the kernel reads both
-        // through one preloaded pointer)
-        HIP_TRY(hipMalloc(&d_step, sizeof(DeStepCtl) * 2 + sizeof(DeRunInfo)));
-        d_run = reinterpret_cast<DeRunInfo*>(d_step + 2);
-        HIP_TRY(hipMemset(d_shared, 0, sizeof(DeShared)));
+        HIP_TRY(hipMalloc(&d_head, sizeof(DeHead)));
+        HIP_TRY(hipMalloc(&d_batch, sizeof(DeBatch)));
+        HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * kDeSegments * kDeCountStride));
+        HIP_TRY(hipMemset(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride));
+        HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
+        HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
+        HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * updates_max));  // two batches: one being planned, one being used
         for (int k = 0; k < 2; ++k)
         {
             HIP_TRY(hipEventCreate(&ev_t0[k]));
             HIP_TRY(hipEventCreate(&ev_t1[k]));
         }
-        // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
-        {
-            // MCMCPP_HIP_DE_FIND_WALKERS: runs of kDeScanRun stream positions one scanning lane takes (read once, here)
-            const char* v = std::getenv("MCMCPP_HIP_DE_FIND_WALKERS");
-            knob_walkers_per_find_wave = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 1;
-            if (knob_walkers_per_find_wave < 1) knob_walkers_per_find_wave = 1;
-            v = std::getenv("MCMCPP_HIP_DE_SCAN_RUN");  // stream positions one scanning lane steps through
-            scan_run = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeScanRun;
-            if (scan_run < 1) scan_run = 1;
-            v = std::getenv("MCMCPP_HIP_DE_DEBUG");
-            knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
-        }
         graph_steps = c.graph_steps == 0 ? 128 : c.graph_steps;
+        // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
         if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
+        replay_steps_max = graph_steps >= 1 ? graph_steps : 16;  // (plain launches: enqueued in groups of this many steps)
+        const int per_block = (64 / lpw) * kWavesPerBlock;
+        update_blocks = (n + per_block - 1) / per_block;
+        partial_waves = update_blocks * kWavesPerBlock;
+        // the run record and, right behind it, the wavefronts' accepted counts of a replay: one allocation (the kernel reaches
+        // both through one preloaded pointer)
+        {
+            const size_t bytes = sizeof(DeRunInfo) + sizeof(uint32_t) * (size_t)replay_steps_max * 2 * (size_t)partial_waves;
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, bytes));
+            d_run = static_cast<DeRunInfo*>(p);
+            HIP_TRY(hipMemset(d_run, 0, bytes));
+        }
         HIP_TRY(hipMemset(d_nacc, 0, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMemset(d_diag, 0, sizeof(Diag)));
         if (c.calc_params_len > 0)
@@ -120,11 +150,9 @@ public:
 
         // the stream (MultiSampler.h:54) and its jump tables: D + 3 draws per update
         pcg_seed(c.seed, c.stream, &state0, &inc);
-        const unsigned per = (unsigned)D + 3u;
         {
-            scan_positions = (int)per * n + kDeMaxShift + 1;
-            const size_t scan_lanes = ((size_t)scan_positions + scan_run - 1) / scan_run;
-            std::vector<Affine128> lo(256), hi((size_t)(n + 255) / 256), small((size_t)(D > kDeMaxShift ? D : kDeMaxShift) + 2);
+            const size_t scan_lanes = ((size_t)positions_max + scan_run - 1) / scan_run;
+            std::vector<Affine128> lo(256), hi((updates_max + 255) / 256), small((size_t)kDeShiftMax + (size_t)D + 2);
             std::vector<Affine128> slo(256), shi((scan_lanes + 255) / 256);
             Affine128 id;
             id.mult = make_u128(0, 1);
@@ -149,9 +177,19 @@ public:
             HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(d_jump_small, small.data(), sizeof(Affine128) * small.size(), hipMemcpyHostToDevice));
         }
-        half_jump = pcg_jump(inc, (unsigned __int128)per * (unsigned)n);
+        batch_jumps.resize((size_t)batch_max + 1);
+        for (int b = 1; b <= batch_max; ++b) batch_jumps[(size_t)b] = pcg_jump(inc, (unsigned __int128)per * (unsigned)n * (unsigned)b);
         threshold = (uint64_t)(0 - (uint64_t)n) % (uint64_t)n;
         gamma = (T)(2.38 / std::sqrt((double)(2 * D)));  // DifferentialEvolution.h:57
+
+        args.calc_params = d_params;
+        args.diag = d_diag;
+        args.inc = inc;
+        args.gamma = gamma;
+        args.jitter_width = (T)2.0e-4;  // DifferentialEvolution.h:120-121
+        args.jitter_low = (T)-1.0e-4;
+        args.tie_eps = sizeof(T) == 8 ? (T)1e-12 : (T)6e-7;
+        args.partial_waves = partial_waves;
         return MCMCPP_HIP_OK;
     }
 
@@ -159,17 +197,17 @@ public:
     {
         if (!pos || !logp) return fail(MCMCPP_HIP_E_ARG, "set_state: null pointer");
         HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(plan_stream));
         HIP_TRY(hipMemcpyAsync(d_pos, pos, sizeof(T) * (size_t)W * D, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_logp, logp, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
         HIP_TRY(hipMemsetAsync(d_diag, 0, sizeof(Diag), stream));
-        DeCtl c[4];
-        std::memset(c, 0, sizeof c);
-        c[0].state = state0;
-        HIP_TRY(hipMemcpyAsync(d_ctl, c, sizeof c, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(d_shared, 0, sizeof(DeShared), stream));
+        DeHead h;
+        std::memset(&h, 0, sizeof h);
+        h.state = state0;
+        HIP_TRY(hipMemcpyAsync(d_head, &h, sizeof h, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride, stream));
         HIP_TRY(hipStreamSynchronize(stream));
-        half_steps = 0;
         steps_since_reset = 0;
         have_state = true;
         return MCMCPP_HIP_OK;
@@ -182,7 +220,7 @@ public:
         const int rc = run_steps(n_saved, interval, chain_out, accepted_per_step);
         if (rc != MCMCPP_HIP_OK && run_touched)
         {
-            // launches went out and the call failed: the walkers are ahead of the host's counters (and the stream may
+            // launches went out and the call failed: the walkers are ahead of the host's counters (and the streams may
             // be left capturing) -- nothing on the device can be trusted until the next set_state
             hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
@@ -192,6 +230,7 @@ public:
                 if (g) (void)hipGraphDestroy(g);
             }
             (void)hipStreamSynchronize(stream);
+            (void)hipStreamSynchronize(plan_stream);
             (void)hipGetLastError();
             have_state = false;
         }
@@ -213,9 +252,7 @@ public:
         int64_t piece = n_saved;
         if (accepted_per_step)
         {
-            const int64_t per_stored = (int64_t)interval * kDeAccSlots * (int64_t)sizeof(uint32_t);
-            if (per_stored > ((int64_t)1 << 30))
-                return fail(MCMCPP_HIP_E_UNSUPPORTED, "run: interval %d is too large to report accepted counts per step; pass NULL for accepted_per_step", interval);
+            const int64_t per_stored = (int64_t)interval * (int64_t)sizeof(uint32_t);
             const int64_t fit = ((int64_t)64 << 20) / per_stored;
             if (piece > fit) piece = fit < 1 ? 1 : fit;
         }
@@ -232,7 +269,7 @@ public:
                 chain_bytes = (size_t)piece * step_bytes;
             }
         }
-        const int64_t acc_piece = accepted_per_step ? piece * (int64_t)interval * kDeAccSlots : 0;
+        const int64_t acc_piece = accepted_per_step ? piece * (int64_t)interval : 0;
         if (accepted_per_step && (size_t)acc_piece > acc_count)
         {
             if (d_acc) HIP_TRY(hipFree(d_acc));
@@ -241,74 +278,20 @@ public:
             HIP_TRY(hipMalloc(&d_acc, sizeof(uint32_t) * (size_t)acc_piece));
             acc_count = (size_t)acc_piece;
         }
-        DeArgs<T>& a = args;
-        std::memset(&a, 0, sizeof a);
-        a.pos = d_pos;
-        a.logp = d_logp;
-        a.n_accept = d_nacc;
-        a.calc_params = d_params;
-        a.ctl = d_ctl;
-        a.shared = d_shared;
-        a.bad = d_bad;
-        a.bad_capacity = bad_capacity;
-        a.scan_positions = scan_positions;
-        a.scan_run = scan_run;
-        a.scan_hi = d_scan_hi;
-        a.scan_lo = d_scan_lo;
-        a.recs = d_recs;
-        a.run = d_run;
-        a.step_ctl = d_step;
-        a.half_jump = half_jump;
-        a.jump_hi = d_jump_hi;
-        a.jump_lo = d_jump_lo;
-        a.jump_small = d_jump_small;
-        a.diag = d_diag;
-        a.threshold = threshold;
-        a.inc = inc;
-        a.gamma = gamma;
-        a.jitter_width = (T)2.0e-4;  // DifferentialEvolution.h:120-121
-        a.jitter_low = (T)-1.0e-4;
-        a.tie_eps = sizeof(T) == 8 ? (T)1e-12 : (T)6e-7;
-        a.n = n;
-        a.dims = D;
-        a.vec_ok = vec_ok;
-        if (knob_debug == 3 && !d_debug) HIP_TRY(hipMalloc(&d_debug, sizeof(unsigned long long) * 2 * 8192));
-        a.debug_times = d_debug;
-        const int per_block = (64 / lpw) * kWavesPerBlock;
-        update_blocks = (n + per_block - 1) / per_block;
-        record_blocks = (n + 64 * kWavesPerBlock - 1) / (64 * kWavesPerBlock);
-        // scanners: a lane per kDeScanRun stream positions (knob: that many runs per lane)
-        {
-            const long lanes = ((long)scan_positions + scan_run - 1) / scan_run;
-            const long per_wg = 64L * kWavesPerBlock * knob_walkers_per_find_wave;
-            find_blocks = (int)((lanes + per_wg - 1) / per_wg);
-            if (find_blocks < 1) find_blocks = 1;
-        }
 
-        // Priming: the planners run one half-step (records) and two half-steps (candidates) ahead of the updates.  Two
-        // planning-only launches bring them there from the stream position the ring holds for the coming half-step.
         run_touched = true;
-        HIP_TRY(hipMemsetAsync(d_shared, 0, offsetof(DeShared, error), stream));  // (the bad-position counters; the error flags stay)
-        launch_step((int)((half_steps + 3) & 3), /*with_update=*/false, /*with_records=*/false);  // bad positions of the coming half-step
-        launch_step((int)((half_steps + 3) & 3), false, true);                                     // its records, positions of the next
-        HIP_TRY(hipGetLastError());
-
         double gpu_ms = 0.0;
         for (int64_t first = 0; first < n_saved; first += piece)
         {
             const int64_t now = n_saved - first < piece ? n_saved - first : piece;
-            if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)(now * interval) * kDeAccSlots, stream));
             {
                 DeRunInfo ri;
                 std::memset(&ri, 0, sizeof ri);
                 ri.chain = chain_out ? d_chain : nullptr;
                 ri.accepted = accepted_per_step ? d_acc : nullptr;
-                ri.interval = interval;
-                DeStepCtl sc[2];
-                std::memset(sc, 0, sizeof sc);
+                ri.interval = (uint32_t)interval;
                 HIP_TRY(hipMemcpyAsync(d_run, &ri, sizeof ri, hipMemcpyHostToDevice, stream));
-                HIP_TRY(hipMemcpyAsync(d_step, sc, sizeof sc, hipMemcpyHostToDevice, stream));
-                HIP_TRY(hipStreamSynchronize(stream));  // (the sources are on this stack frame)
+                HIP_TRY(hipStreamSynchronize(stream));  // (the source is on this stack frame)
             }
             HIP_TRY(hipEventRecord(ev_t0[0], stream));
             int rc = enqueue_steps(now * interval);
@@ -317,10 +300,7 @@ public:
             if (chain_out)
                 HIP_TRY(hipMemcpyAsync(static_cast<char*>(chain_out) + (size_t)first * step_bytes, d_chain, (size_t)now * step_bytes, hipMemcpyDeviceToHost, stream));
             if (accepted_per_step)
-            {
-                acc_host.resize((size_t)(now * interval) * kDeAccSlots);
-                HIP_TRY(hipMemcpyAsync(acc_host.data(), d_acc, sizeof(uint32_t) * acc_host.size(), hipMemcpyDeviceToHost, stream));
-            }
+                HIP_TRY(hipMemcpyAsync(accepted_per_step + first * interval, d_acc, sizeof(uint32_t) * (size_t)(now * interval), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             {
                 float ms = 0.f;
@@ -328,77 +308,129 @@ public:
                 gpu_ms += ms;
             }
             if (chain_out) publish_stored(first + now);
-            if (accepted_per_step)
-                for (int64_t e = 0; e < now * interval; ++e)
-                {
-                    uint32_t sum = 0;
-                    for (int q = 0; q < kDeAccSlots; ++q) sum += acc_host[(size_t)e * kDeAccSlots + q];
-                    accepted_per_step[first * interval + e] = sum;
-                }
         }
         steps_since_reset += (uint64_t)total;
-        if (d_debug)
-        {
-            // diagnostics: when the workgroups of the LAST launch started and ended, by role (us from the first start)
-            const int grid = update_blocks + record_blocks + find_blocks;
-            std::vector<unsigned long long> t((size_t)2 * grid);
-            HIP_TRY(hipMemcpy(t.data(), d_debug, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
-            unsigned long long t0 = ~0ULL;
-            for (int b = 0; b < grid; ++b) t0 = t[2 * b] < t0 ? t[2 * b] : t0;
-            const char* names[3] = {"records", "scan", "update"};
-            const int lo[3] = {0, record_blocks, record_blocks + find_blocks}, hi[3] = {record_blocks, record_blocks + find_blocks, grid};
-            for (int r = 0; r < 3; ++r)
-            {
-                double s0 = 1e9, s1 = 0, e0 = 1e9, e1 = 0;
-                for (int b = lo[r]; b < hi[r]; ++b)
-                {
-                    const double st = (t[2 * b] - t0) * 0.01, en = (t[2 * b + 1] - t0) * 0.01;
-                    s0 = st < s0 ? st : s0, s1 = st > s1 ? st : s1, e0 = en < e0 ? en : e0, e1 = en > e1 ? en : e1;
-                }
-                std::fprintf(stderr, "[de debug] %-8s %4d workgroups: start %.2f..%.2f us, end %.2f..%.2f us\n", names[r], hi[r] - lo[r], s0, s1, e0, e1);
-            }
-        }
-        DeShared sh;
-        HIP_TRY(hipMemcpy(&sh, d_shared, sizeof sh, hipMemcpyDeviceToHost));
-        last_ms = gpu_ms;  // GPU time of the step launches between HIP events on the launch stream (transfers excluded)
+        DeHead h;
+        HIP_TRY(hipMemcpy(&h, d_head, sizeof h, hipMemcpyDeviceToHost));
+        last_ms = gpu_ms;  // GPU time of the launches (planning included) between HIP events on the launch stream (transfers excluded)
         last_launches = 2 * total;
         host_wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (sh.error)
+        if (h.error)
         {
             have_state = false;
             return fail(MCMCPP_HIP_E_UNSUPPORTED,
                         "differential evolution: the random stream could not be followed (flags %u: 1 = more than %d draws thrown away in one "
-                        "half-step, 2 = more than %d possible starts among the bad positions, 4 = one update threw away more than %d draws); the state is undefined, call set_state",
-                        sh.error, kDeMaxShift, kDeMaxEvents, kDeWindow - 2);
+                        "batch of half-steps, 2 = more bad stream positions or events than the planner's lists hold, 4 = one update threw away more than %d draws); the state "
+                        "is undefined, call set_state",
+                        h.error, kDeShiftMax, kDeWindow - 2);
         }
         return MCMCPP_HIP_OK;
     }
 
-    // one launch: the update of half-step `h4` (mod 4) beside the planning of the two half-steps behind it
-    void launch_step(int h4, bool with_update, bool with_records)
+    // the three planning launches of `count` half-steps, records into buffer `buf`
+    void launch_plan(int count, int buf, hipStream_t st)
     {
-        DeArgs<T> a = args;
-        a.half_step_mod4 = h4;
-        a.update_blocks = with_update ? update_blocks : 0;
-        a.record_blocks = with_records ? record_blocks : 0;
-        unsigned grid = (unsigned)(a.update_blocks + a.record_blocks + find_blocks);
-        // timing diagnostics only (MCMCPP_HIP_DE_DEBUG; the chain is wrong): 1 = regular launches without planners, 2 = without updates
-        if (with_update && knob_debug == 1) grid = (unsigned)a.update_blocks;
-        if (with_update && knob_debug == 2) a.update_blocks = 0, grid = (unsigned)(a.record_blocks + find_blocks);
-        update_fn(a, grid, stream);
+        const unsigned per = (unsigned)D + 3u;
+        DePlanArgs p;
+        std::memset(&p, 0, sizeof p);
+        p.head = d_head;
+        p.batch = d_batch;
+        p.bad = d_bad;
+        p.counts = d_counts;
+        p.scan_hi = d_scan_hi;
+        p.scan_lo = d_scan_lo;
+        p.jump_hi = d_jump_hi;
+        p.jump_lo = d_jump_lo;
+        p.jump_small = d_jump_small;
+        p.batch_jump = batch_jumps[(size_t)count];
+        p.inc = inc;
+        p.threshold = threshold;
+        p.n = n;
+        p.dims = D;
+        p.updates = n * count;
+        p.positions = (int)((long long)per * (long long)(p.updates - 1) + kDeShiftMax + 1);
+        p.scan_run = scan_run;
+        p.seg_len = (p.positions + kDeSegments - 1) / kDeSegments;
+        p.bad_capacity = bad_capacity;
+        const long long lanes = ((long long)p.positions + scan_run - 1) / scan_run;
+        hipLaunchKernelGGL(de_scan_kernel, dim3((unsigned)((lanes + kDePlanThreads - 1) / kDePlanThreads)), dim3(kDePlanThreads), 0, st, p);
+        hipLaunchKernelGGL(de_resolve_kernel, dim3(1), dim3(kDePlanThreads), 0, st, p);
+        hipLaunchKernelGGL((de_records_kernel<T>), dim3((unsigned)((p.updates + kDePlanThreads - 1) / kDePlanThreads)), dim3(kDePlanThreads), 0, st, p,
+                           d_recs + (size_t)buf * (size_t)batch_max * (size_t)n);
     }
 
-    // hipGraph of `steps` ensemble steps that start at half-step residue `r0` (0 or 2)
-    int graph_for(int steps, int r0, hipGraphExec_t* out)
+    // `steps` ensemble steps (at most replay_steps_max) on the launch stream: batches of up to batch_max half-steps, the
+    // planning of batch b + 1 on the planning stream beside the updates of batch b; behind them the accepted counts and
+    // the run record.  Under stream capture this becomes the replay's graph (the event waits its edges).
+    int enqueue_replay(int steps)
     {
-        const size_t key = (size_t)steps * 2 + (size_t)(r0 >> 1);
+        const int halves = 2 * steps;
+        const int batches = (halves + batch_max - 1) / batch_max;
+        while ((int)events.size() < 2 * batches + 1)
+        {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            events.push_back(e);
+        }
+        hipEvent_t* planned = events.data();            // [batches]
+        hipEvent_t* updated = events.data() + batches;  // [batches]
+        hipEvent_t fork = events[2 * (size_t)batches];
+        const bool overlap = knob_overlap && batches > 1;
+        hipStream_t ps = overlap ? plan_stream : stream;
+        auto count_of = [&](int b) { return halves - b * batch_max < batch_max ? halves - b * batch_max : batch_max; };
+        if (overlap)
+        {
+            HIP_TRY(hipEventRecord(fork, stream));
+            HIP_TRY(hipStreamWaitEvent(ps, fork, 0));
+        }
+        if (knob_debug != 1) launch_plan(count_of(0), 0, ps);
+        if (overlap) HIP_TRY(hipEventRecord(planned[0], ps));
+        typename LaunchTable<T>::DeLaunch l;
+        l.pos = d_pos;
+        l.logp = d_logp;
+        l.n_accept = d_nacc;
+        l.jump_small = d_jump_small;
+        l.run = d_run;
+        l.n = n;
+        l.dims = D;
+        l.vec_ok = vec_ok;
+        for (int b = 0; b < batches; ++b)
+        {
+            if (b + 1 < batches)
+            {
+                // batch b + 1 is planned into the buffer batch b - 1 was read from
+                if (overlap && b >= 1) HIP_TRY(hipStreamWaitEvent(ps, updated[b - 1], 0));
+                if (knob_debug != 1) launch_plan(count_of(b + 1), (b + 1) & 1, ps);
+                if (overlap) HIP_TRY(hipEventRecord(planned[b + 1], ps));
+            }
+            if (overlap) HIP_TRY(hipStreamWaitEvent(stream, planned[b], 0));
+            const int count = count_of(b);
+            for (int j = 0; j < count && knob_debug != 2; ++j)
+            {
+                const int h = b * batch_max + j;  // half-step inside the replay
+                l.recs = d_recs + ((size_t)(b & 1) * (size_t)batch_max + (size_t)j) * (size_t)n;
+                l.color = h & 1;
+                l.step = h >> 1;
+                update_fn(l, args, (unsigned)update_blocks, stream);
+            }
+            if (overlap && b + 2 < batches) HIP_TRY(hipEventRecord(updated[b], stream));
+        }
+        hipLaunchKernelGGL(de_accepted_kernel, dim3((unsigned)steps), dim3(256), 0, stream, d_run, partial_waves);
+        hipLaunchKernelGGL(de_advance_kernel, dim3(1), dim3(1), 0, stream, d_run, steps);
+        return MCMCPP_HIP_OK;
+    }
+
+    // hipGraph of `steps` ensemble steps
+    int graph_for(int steps, hipGraphExec_t* out)
+    {
+        const size_t key = (size_t)steps;
         if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
         if (!graph_cache[key])
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            for (int s = 0; s < steps; ++s)
-                for (int c = 0; c < 2; ++c) launch_step((r0 + 2 * s + c) & 3, true, true);
+            int rc = enqueue_replay(steps);
+            if (rc) return rc;
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -414,24 +446,20 @@ public:
         int64_t left = steps;
         while (left > 0)
         {
-            const int r0 = (int)(half_steps & 3);
+            const int now = (int)(left < replay_steps_max ? left : replay_steps_max);
             if (graph_steps >= 1)
             {
-                const int now = (int)(left < graph_steps ? left : graph_steps);
                 hipGraphExec_t ex = nullptr;
-                int rc = graph_for(now, r0, &ex);
+                int rc = graph_for(now, &ex);
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
-                half_steps += 2 * (uint64_t)now;
-                left -= now;
             }
             else
             {
-                launch_step(r0, true, true);
-                launch_step((r0 + 1) & 3, true, true);
-                half_steps += 2;
-                left -= 1;
+                int rc = enqueue_replay(now);
+                if (rc) return rc;
             }
+            left -= now;
         }
         HIP_TRY(hipGetLastError());
         return MCMCPP_HIP_OK;
@@ -482,9 +510,9 @@ public:
         }
         if (redraws)
         {
-            DeCtl c;
-            HIP_TRY(hipMemcpy(&c, d_ctl + (half_steps & 3), sizeof c, hipMemcpyDeviceToHost));
-            *redraws = c.extra_total;  // every draw thrown away so far (bounded_rand, ind2 == ind1)
+            DeHead h;
+            HIP_TRY(hipMemcpy(&h, d_head, sizeof h, hipMemcpyDeviceToHost));
+            *redraws = h.extra_total;  // every draw thrown away so far (bounded_rand, ind2 == ind1)
         }
         return MCMCPP_HIP_OK;
     }
@@ -547,7 +575,8 @@ private:
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
         for (hipGraphExec_t ex : graph_cache)
             if (ex) (void)hipGraphExecDestroy(ex);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_ctl, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_shared, d_recs, d_step, d_bad, d_scan_lo, d_scan_hi, d_debug};
+        if (plan_stream) (void)hipStreamSynchronize(plan_stream);
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_head, d_batch, d_counts, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_recs, d_run, d_bad, d_scan_lo, d_scan_hi};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         for (int k = 0; k < 2; ++k)
@@ -555,6 +584,9 @@ private:
             if (ev_t0[k]) (void)hipEventDestroy(ev_t0[k]);
             if (ev_t1[k]) (void)hipEventDestroy(ev_t1[k]);
         }
+        for (hipEvent_t e : events)
+            if (e) (void)hipEventDestroy(e);
+        if (plan_stream) (void)hipStreamDestroy(plan_stream);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 
@@ -567,27 +599,29 @@ private:
     T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_chain = nullptr;
     uint32_t *d_nacc = nullptr, *d_acc = nullptr;
     Diag* d_diag = nullptr;
-    DeCtl* d_ctl = nullptr;
-    DeShared* d_shared = nullptr;
+    DeHead* d_head = nullptr;
+    DeBatch* d_batch = nullptr;
+    uint32_t* d_counts = nullptr;
     DeBad* d_bad = nullptr;
-    unsigned long long* d_debug = nullptr;
     Affine128 *d_scan_lo = nullptr, *d_scan_hi = nullptr;
-    int bad_capacity = 0, scan_positions = 0, scan_run = kDeScanRun;
+    int bad_capacity = 0, scan_run = kDeScanRun, batch_max = kDeBatchMax;
+    long long positions_max = 0;
     DeRec<T>* d_recs = nullptr;
     DeRunInfo* d_run = nullptr;
-    DeStepCtl* d_step = nullptr;
     DeArgs<T> args;
-    int update_blocks = 0, record_blocks = 0, find_blocks = 1, graph_steps = 128, knob_walkers_per_find_wave = 2, knob_debug = 0;
+    int update_blocks = 0, partial_waves = 0, graph_steps = 128, replay_steps_max = 128, knob_debug = 0;
+    bool knob_overlap = true;
+    hipStream_t plan_stream = nullptr;  // the planning launches of the next batch, beside the updates of this one
+    std::vector<hipEvent_t> events;     // fork/join between the two streams (graph edges under capture)
+    std::vector<Affine128> batch_jumps; // [half-steps of a batch]: (D+3) * n * that many draws
     bool run_touched = false;
     hipEvent_t ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
     std::vector<hipGraphExec_t> graph_cache;
 
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_jump_small = nullptr;
     size_t chain_bytes = 0, acc_count = 0;
-    std::vector<uint32_t> acc_host;
     U128 state0, inc;
-    Affine128 half_jump;
-    uint64_t threshold = 0, half_steps = 0, steps_since_reset = 0;
+    uint64_t threshold = 0, steps_since_reset = 0;
     T gamma = 0;
     double last_ms = 0.0;
     int64_t last_launches = 0;

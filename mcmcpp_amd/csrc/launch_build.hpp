@@ -93,11 +93,11 @@ void launch_calc(const T* pos, T* out, const T* prm, long long count, int dims, 
 }
 
 template <class T, class Calc, int EPL, int LPW>
-void launch_de(const DeArgs<T>& a, unsigned grid, hipStream_t st)
+void launch_de(const typename LaunchTable<T>::DeLaunch& l, const DeArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(a.dims);
-    hipLaunchKernelGGL((de_step_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, a.pos, a.logp, a.n_accept, a.recs, a.jump_small, a.step_ctl,
-                       a.n, de_hot_bits(a.dims, a.half_step_mod4, a.vec_ok), (int)grid - a.update_blocks, a);
+    const size_t lds = LdsLayout<T, Calc, EPL>::bytes(l.dims);
+    hipLaunchKernelGGL((de_update_kernel<T, Calc, EPL, LPW>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, l.pos, l.logp, l.n_accept, l.recs, l.jump_small, l.run, l.n,
+                       de_hot_bits(l.dims, l.color, l.vec_ok), l.step, a);
 }
 
 template <class T, class Calc, int LPWLOG, int EPLSHIFT>

@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D43000Fu;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430010u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -33,8 +33,19 @@ struct LaunchTable
     // (generic) or 32 per colour (matrix-core variant)
     HalfStepFn full_step[kLpwLevels][kMaxEplShift];
     HalfStepFn full_step_mc[kLpwLevels][kMaxEplShift];
-    // Mover::DifferentialEvolution (diffevo_kernel.hpp): one launch updates a whole half and plans the stream of the next two
-    typedef void (*DeFn)(const DeArgs<T>&, unsigned grid, hipStream_t);
+    // Mover::DifferentialEvolution (diffevo_kernel.hpp): one launch updates a whole half from the records of that half-step
+    struct DeLaunch
+    {
+        T* pos;
+        T* logp;
+        uint32_t* n_accept;
+        const DeRec<T>* recs;  // the n records of this half-step
+        const Affine128* jump_small;
+        DeRunInfo* run;
+        int n, dims, color, vec_ok;
+        int step;  // ensemble step inside the replay
+    };
+    typedef void (*DeFn)(const DeLaunch&, const DeArgs<T>&, unsigned grid, hipStream_t);
     DeFn de_update[kLpwLevels][kMaxEplShift];
 };
 

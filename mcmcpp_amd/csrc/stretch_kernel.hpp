@@ -305,6 +305,18 @@ __device__ __forceinline__ void store_slice(T* row, int i0, int D, bool vec_ok, 
     }
 }
 
+// A pointer that was loaded from memory (a run record's chain or counter address) is a generic pointer to the compiler:
+// accesses through it become flat_* instructions, which tick both memory counters, and in front of which the compiler
+// waits for every outstanding global operation (seen in the differential-evolution update kernel: a wait for the row stores' acknowledgement at
+// the end of every updating wavefront).  Device memory is all such a pointer ever holds: say so.
+template <class P>
+__device__ __forceinline__ P* assume_global(P* p)
+{
+    typedef __attribute__((address_space(1))) unsigned char GlobalByte;
+    // (through the global address space and back: the compiler's address-space inference follows the cast)
+    return reinterpret_cast<P*>((unsigned char*)reinterpret_cast<GlobalByte*>(reinterpret_cast<unsigned long long>(p)));
+}
+
 __device__ __forceinline__ double dev_log(double x) { return fast_log(x); }
 __device__ __forceinline__ float dev_log(float x) { return logf(x); }
 __device__ __forceinline__ double dev_abs(double x) { return fabs(x); }

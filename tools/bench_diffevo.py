@@ -20,14 +20,15 @@ def main():
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
     P = ar1_precision(D, 0.5, np.float64).ravel()
     pos = po.init_positions(po.F64, W, D, salt=0)
-    if os.environ.get("DE_CALC") == "iso":  # (experiments: the update without the dense calculator)
-        s = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    if os.environ.get("DE_CALC"):  # (experiments: launch times only, e.g. with the diagnostic knobs that leave the chain wrong)
+        iso = os.environ["DE_CALC"] == "iso"
+        s = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN if iso else capi.CALC_DENSE_GAUSSIAN, None if iso else P, seed=0, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
         lp = s.calc_logp(pos)
         s.set_state(pos, lp)
         s.run(1, 50, save_chain=False)
         s.run(20, 100, save_chain=False)
         gpu_ms, launches = s.last_run_timing()
-        print("iso calculator: %.2f us per launch" % (gpu_ms * 1e3 / launches))
+        print("%s calculator: %.2f us per half-step" % (os.environ["DE_CALC"], gpu_ms * 1e3 / launches))
         return
     s = capi.HipSampler(W, D, capi.CALC_DENSE_GAUSSIAN, P, seed=0, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
     lp = s.calc_logp(pos)
