@@ -1,9 +1,8 @@
 // diffevo.hip -- host side of Mover::DifferentialEvolution on gfx950 (reference
 // MCMCpp/Movers/DifferentialEvolution.h:80-112 inside EnsembleSampler::performStep, EnsembleSampler.h:342-354).
-// See diffevo_kernel.hpp for the scheme: the random stream is planned a batch of half-steps at a time (scan, resolve,
-// records) on a second HIP stream beside the update launches of the batch before, one update launch per half-step; a
-// run is replayed from hipGraphs whose edges are the event waits between the two streams; the stream head, the error
-// flags and the per-run counters travel in device memory.
+// See diffevo_kernel.hpp for the scheme: one update launch per half-step; the random stream is planned a batch of half-steps
+// at a time (scan, resolve, records) by two launches at every batch boundary; a run is replayed from hipGraphs; the stream
+// head, the error flags and the per-run counters travel in device memory.
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -13,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "diffevo_plan.hpp"
@@ -69,48 +69,52 @@ public:
             own_stream = true;
         }
 
-        HIP_TRY(hipStreamCreateWithFlags(&plan_stream, hipStreamNonBlocking));
         {
             const char* v = std::getenv("MCMCPP_HIP_DE_SCAN_RUN");  // stream positions one scanning lane steps through
             scan_run = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeScanRun;
             if (scan_run < 1) scan_run = 1;
-            v = std::getenv("MCMCPP_HIP_DE_BATCH");  // half-steps planned by one batch of planning launches
+            v = std::getenv("MCMCPP_HIP_DE_BATCH");  // half-steps planned together
             batch_max = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeBatchMax;
-            v = std::getenv("MCMCPP_HIP_DE_DEBUG");  // timing diagnostics (the chain is wrong): 1 = the update launches alone, 2 = the planning alone
+            v = std::getenv("MCMCPP_HIP_DE_DEBUG");  // timing diagnostics (the chain is wrong): 1 = the update launches alone, 2 = the planning launches alone
             knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
-            v = std::getenv("MCMCPP_HIP_DE_OVERLAP");  // 0: planning in the launch stream, in front of the updates it plans
-            knob_overlap = (v && *v) ? (int)std::strtol(v, nullptr, 10) != 0 : true;
         }
         // the batch: as many half-steps as the position counters (32 bits), the resolver's lists and a sensible amount of
-        // record memory (128 MiB) allow
+        // record memory (256 MiB) allow
         const unsigned per = (unsigned)D + 3u;
         {
             long long b = batch_max < 1 ? 1 : (batch_max > kDeBatchMax ? kDeBatchMax : batch_max);
             const long long by_positions = ((1LL << 30) - kDeShiftMax - 1) / ((long long)per * n);
-            const long long by_lists = (kDeMaxBad * 5LL / 8) / per;
-            const long long by_records = (4LL << 20) / n;
+            const long long by_lists = (kDeMaxBad * 5LL / 8 - (kDeShiftMax + 1) / n) / per;
+            const long long by_records = (8LL << 20) / n;
             b = b < by_positions ? b : by_positions;
             b = b < by_lists ? b : by_lists;
             b = b < by_records ? b : by_records;
-            if (by_positions < 1) return fail(MCMCPP_HIP_E_UNSUPPORTED, "differential evolution: %d walkers x %d parameters exceed the planner's 2^30 stream positions per half-step", W, D);
-            batch_max = b < 1 ? 1 : (int)b;
+            if (b < 1)
+                return fail(MCMCPP_HIP_E_UNSUPPORTED, "differential evolution: %d walkers x %d parameters exceed what the stream planner holds (per half-step: 2^30 stream "
+                            "positions, 8 Mi updates)", W, D);
+            batch_max = (int)b;
         }
         const size_t updates_max = (size_t)batch_max * n;
         positions_max = (long long)per * (long long)(updates_max - 1) + kDeShiftMax + 1;
-        // a batch lists about (D + 3) bad positions per half-step (one position in n is bad), spread evenly over the lists
-        bad_capacity = 4 * (int)((per * (unsigned)batch_max + kDeSegments - 1) / kDeSegments) + 64;
+        // one stream position in n is bad: a batch lists about (D + 3) of them per half-step (and as many again as the
+        // kDeShiftMax positions behind its end hold, which matters for tiny ensembles), spread evenly over the lists
+        {
+            const long long expected = positions_max / n + 1;
+            bad_capacity = (int)(4 * ((expected + kDeSegments - 1) / kDeSegments) + 64);
+            const long long cap = 2 * expected + 512;
+            resolve_capacity = cap > kDeMaxBad ? kDeMaxBad : (int)cap;
+        }
+        scan_blocks = (int)(((positions_max + scan_run - 1) / scan_run + kDePlanThreads - 1) / kDePlanThreads);
 
         HIP_TRY(hipMalloc(&d_pos, sizeof(T) * (size_t)W * D));
         HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
         HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
-        HIP_TRY(hipMalloc(&d_head, sizeof(DeHead)));
-        HIP_TRY(hipMalloc(&d_batch, sizeof(DeBatch)));
         HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * kDeSegments * kDeCountStride));
         HIP_TRY(hipMemset(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride));
         HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
         HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
-        HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * 2 * updates_max));  // two batches: one being planned, one being used
+        HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * updates_max));  // the records of the batch being stepped through
         for (int k = 0; k < 2; ++k)
         {
             HIP_TRY(hipEventCreate(&ev_t0[k]));
@@ -123,8 +127,10 @@ public:
         const int per_block = (64 / lpw) * kWavesPerBlock;
         update_blocks = (n + per_block - 1) / per_block;
         partial_waves = update_blocks * kWavesPerBlock;
-        // the run record and, right behind it, the wavefronts' accepted counts of a replay: one allocation (the kernel reaches
-        // both through one preloaded pointer)
+        HIP_TRY(hipMalloc(&d_head, sizeof(DeHead)));
+        HIP_TRY(hipMalloc(&d_batch, sizeof(DeBatch) * 2));  // batch b resolves into record b & 1
+        // the run record and, right behind it, the wavefronts' accepted counts of a replay: one allocation (the update kernel
+        // reaches both through one preloaded pointer)
         {
             const size_t bytes = sizeof(DeRunInfo) + sizeof(uint32_t) * (size_t)replay_steps_max * 2 * (size_t)partial_waves;
             void* p = nullptr;
@@ -166,19 +172,21 @@ public:
             slo[0] = shi[0] = id;
             for (size_t j = 1; j < slo.size(); ++j) slo[j] = compose(step_r, slo[j - 1]);
             for (size_t m = 1; m < shi.size(); ++m) shi[m] = compose(step_rb, shi[m - 1]);
-            HIP_TRY(hipMalloc(&d_scan_lo, sizeof(Affine128) * slo.size()));
-            HIP_TRY(hipMalloc(&d_scan_hi, sizeof(Affine128) * shi.size()));
-            HIP_TRY(hipMemcpy(d_scan_lo, slo.data(), sizeof(Affine128) * slo.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_scan_hi, shi.data(), sizeof(Affine128) * shi.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc(&d_jump_lo, sizeof(Affine128) * lo.size()));
-            HIP_TRY(hipMalloc(&d_jump_hi, sizeof(Affine128) * hi.size()));
-            HIP_TRY(hipMalloc(&d_jump_small, sizeof(Affine128) * small.size()));
-            HIP_TRY(hipMemcpy(d_jump_lo, lo.data(), sizeof(Affine128) * lo.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(d_jump_small, small.data(), sizeof(Affine128) * small.size(), hipMemcpyHostToDevice));
+            std::vector<Affine128> all;  // one allocation
+            all.insert(all.end(), small.begin(), small.end());
+            all.insert(all.end(), slo.begin(), slo.end());
+            all.insert(all.end(), lo.begin(), lo.end());
+            all.insert(all.end(), hi.begin(), hi.end());
+            all.insert(all.end(), shi.begin(), shi.end());
+            HIP_TRY(hipMalloc(&d_tables, sizeof(Affine128) * all.size()));
+            HIP_TRY(hipMemcpy(d_tables, all.data(), sizeof(Affine128) * all.size(), hipMemcpyHostToDevice));
+            d_jump_small = d_tables;
+            d_scan_lo = d_jump_small + small.size();
+            d_jump_lo = d_scan_lo + slo.size();
+            d_jump_hi = d_jump_lo + lo.size();
+            d_scan_hi = d_jump_hi + hi.size();
         }
-        batch_jumps.resize((size_t)batch_max + 1);
-        for (int b = 1; b <= batch_max; ++b) batch_jumps[(size_t)b] = pcg_jump(inc, (unsigned __int128)per * (unsigned)n * (unsigned)b);
+        batch_jump = pcg_jump(inc, (unsigned __int128)per * (unsigned)n * (unsigned)batch_max);
         threshold = (uint64_t)(0 - (uint64_t)n) % (uint64_t)n;
         gamma = (T)(2.38 / std::sqrt((double)(2 * D)));  // DifferentialEvolution.h:57
 
@@ -197,7 +205,6 @@ public:
     {
         if (!pos || !logp) return fail(MCMCPP_HIP_E_ARG, "set_state: null pointer");
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamSynchronize(plan_stream));
         HIP_TRY(hipMemcpyAsync(d_pos, pos, sizeof(T) * (size_t)W * D, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(d_logp, logp, sizeof(T) * (size_t)W, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(uint32_t) * (size_t)W, stream));
@@ -209,6 +216,8 @@ public:
         HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         steps_since_reset = 0;
+        half_steps = 0;
+        primed = false;
         have_state = true;
         return MCMCPP_HIP_OK;
     }
@@ -220,7 +229,7 @@ public:
         const int rc = run_steps(n_saved, interval, chain_out, accepted_per_step);
         if (rc != MCMCPP_HIP_OK && run_touched)
         {
-            // launches went out and the call failed: the walkers are ahead of the host's counters (and the streams may
+            // launches went out and the call failed: the walkers are ahead of the host's counters (and the stream may
             // be left capturing) -- nothing on the device can be trusted until the next set_state
             hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone)
@@ -230,7 +239,6 @@ public:
                 if (g) (void)hipGraphDestroy(g);
             }
             (void)hipStreamSynchronize(stream);
-            (void)hipStreamSynchronize(plan_stream);
             (void)hipGetLastError();
             have_state = false;
         }
@@ -327,14 +335,13 @@ public:
         return MCMCPP_HIP_OK;
     }
 
-    // the three planning launches of `count` half-steps, records into buffer `buf`
-    void launch_plan(int count, int buf, hipStream_t st)
+    // what every planning launch of this handle shares (batches are always batch_max half-steps long)
+    DePlanArgs plan_args() const
     {
         const unsigned per = (unsigned)D + 3u;
         DePlanArgs p;
         std::memset(&p, 0, sizeof p);
         p.head = d_head;
-        p.batch = d_batch;
         p.bad = d_bad;
         p.counts = d_counts;
         p.scan_hi = d_scan_hi;
@@ -342,49 +349,55 @@ public:
         p.jump_hi = d_jump_hi;
         p.jump_lo = d_jump_lo;
         p.jump_small = d_jump_small;
-        p.batch_jump = batch_jumps[(size_t)count];
+        p.batch_jump = batch_jump;
         p.inc = inc;
         p.threshold = threshold;
         p.n = n;
         p.dims = D;
-        p.updates = n * count;
+        p.updates = n * batch_max;
         p.positions = (int)((long long)per * (long long)(p.updates - 1) + kDeShiftMax + 1);
         p.scan_run = scan_run;
         p.seg_len = (p.positions + kDeSegments - 1) / kDeSegments;
         p.bad_capacity = bad_capacity;
-        const long long lanes = ((long long)p.positions + scan_run - 1) / scan_run;
-        hipLaunchKernelGGL(de_scan_kernel, dim3((unsigned)((lanes + kDePlanThreads - 1) / kDePlanThreads)), dim3(kDePlanThreads), 0, st, p);
-        hipLaunchKernelGGL(de_resolve_kernel, dim3(1), dim3(kDePlanThreads), 0, st, p);
-        hipLaunchKernelGGL((de_records_kernel<T>), dim3((unsigned)((p.updates + kDePlanThreads - 1) / kDePlanThreads)), dim3(kDePlanThreads), 0, st, p,
-                           d_recs + (size_t)buf * (size_t)batch_max * (size_t)n);
+        return p;
     }
 
-    // `steps` ensemble steps (at most replay_steps_max) on the launch stream: batches of up to batch_max half-steps, the
-    // planning of batch b + 1 on the planning stream beside the updates of batch b; behind them the accepted counts and
-    // the run record.  Under stream capture this becomes the replay's graph (the event waits its edges).
-    int enqueue_replay(int steps)
+    // the scan of the batch the stream head stands in front of
+    void launch_scan() { hipLaunchKernelGGL(de_scan_kernel, dim3((unsigned)scan_blocks), dim3(kDePlanThreads), 0, stream, plan_args()); }
+
+    // the resolve of batch `resolve_batch` (scanned before; < 0: none) beside the records of batch `record_batch` (resolved
+    // before; < 0: none), one launch
+    void launch_resolve_records(long long resolve_batch, long long record_batch)
     {
-        const int halves = 2 * steps;
-        const int batches = (halves + batch_max - 1) / batch_max;
-        while ((int)events.size() < 2 * batches + 1)
-        {
-            hipEvent_t e = nullptr;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            events.push_back(e);
-        }
-        hipEvent_t* planned = events.data();            // [batches]
-        hipEvent_t* updated = events.data() + batches;  // [batches]
-        hipEvent_t fork = events[2 * (size_t)batches];
-        const bool overlap = knob_overlap && batches > 1;
-        hipStream_t ps = overlap ? plan_stream : stream;
-        auto count_of = [&](int b) { return halves - b * batch_max < batch_max ? halves - b * batch_max : batch_max; };
-        if (overlap)
-        {
-            HIP_TRY(hipEventRecord(fork, stream));
-            HIP_TRY(hipStreamWaitEvent(ps, fork, 0));
-        }
-        if (knob_debug != 1) launch_plan(count_of(0), 0, ps);
-        if (overlap) HIP_TRY(hipEventRecord(planned[0], ps));
+        DePlanArgs p = plan_args();
+        p.batch = d_batch + (resolve_batch >= 0 ? (resolve_batch & 1) : 0);
+        const int record_blocks = record_batch >= 0 ? (p.updates + kDePlanThreads - 1) / kDePlanThreads : 0;
+        size_t lds = record_blocks ? sizeof(DePlan) * kDeMaxEvents : 0;
+        const size_t need = resolve_batch >= 0 ? de_resolve_lds_bytes(resolve_capacity, D + 3) : 0;
+        lds = need > lds ? need : lds;
+        hipLaunchKernelGGL((de_resolve_records_kernel<T>), dim3((unsigned)(record_blocks + (resolve_batch >= 0 ? 1 : 0))), dim3(kDePlanThreads), lds, stream, p,
+                           resolve_batch >= 0 ? 1 : 0, resolve_capacity, d_batch + (record_batch >= 0 ? (record_batch & 1) : 0), d_recs);
+    }
+
+    // Behind a set_state: batch 0 scanned and resolved, batch 1 scanned -- what the boundary in front of a batch finds
+    // (see enqueue_replay).
+    int prime()
+    {
+        launch_scan();
+        launch_resolve_records(0, -1);
+        launch_scan();
+        HIP_TRY(hipGetLastError());
+        primed = true;
+        return MCMCPP_HIP_OK;
+    }
+
+    // `steps` ensemble steps (at most replay_steps_max) from half-step h0 (counted from the set_state) on the launch stream:
+    // one update launch per half-step; in front of the first half-step of batch b the boundary's two planning launches --
+    // the resolve of batch b + 1 (scanned at the boundary before) beside the records of batch b (resolved at the boundary
+    // before), then the scan of batch b + 2 from the stream head that resolve has left.  Behind the steps: the accepted
+    // counts and the run record.
+    int enqueue_replay(int steps, uint64_t h0)
+    {
         typename LaunchTable<T>::DeLaunch l;
         l.pos = d_pos;
         l.logp = d_logp;
@@ -394,55 +407,57 @@ public:
         l.n = n;
         l.dims = D;
         l.vec_ok = vec_ok;
-        for (int b = 0; b < batches; ++b)
+        for (int i = 0; i < 2 * steps; ++i)
         {
-            if (b + 1 < batches)
+            const uint64_t h = h0 + (uint64_t)i;
+            const uint64_t b = h / (uint64_t)batch_max;
+            const int j = (int)(h % (uint64_t)batch_max);
+            if (j == 0 && knob_debug != 1)
             {
-                // batch b + 1 is planned into the buffer batch b - 1 was read from
-                if (overlap && b >= 1) HIP_TRY(hipStreamWaitEvent(ps, updated[b - 1], 0));
-                if (knob_debug != 1) launch_plan(count_of(b + 1), (b + 1) & 1, ps);
-                if (overlap) HIP_TRY(hipEventRecord(planned[b + 1], ps));
+                launch_resolve_records((long long)b + 1, (long long)b);
+                launch_scan();
             }
-            if (overlap) HIP_TRY(hipStreamWaitEvent(stream, planned[b], 0));
-            const int count = count_of(b);
-            for (int j = 0; j < count && knob_debug != 2; ++j)
-            {
-                const int h = b * batch_max + j;  // half-step inside the replay
-                l.recs = d_recs + ((size_t)(b & 1) * (size_t)batch_max + (size_t)j) * (size_t)n;
-                l.color = h & 1;
-                l.step = h >> 1;
-                update_fn(l, args, (unsigned)update_blocks, stream);
-            }
-            if (overlap && b + 2 < batches) HIP_TRY(hipEventRecord(updated[b], stream));
+            if (knob_debug == 2) continue;
+            l.recs = d_recs + (size_t)j * (size_t)n;
+            l.color = (int)(h & 1);
+            l.step = i >> 1;
+            update_fn(l, args, (unsigned)update_blocks, stream);
         }
         hipLaunchKernelGGL(de_accepted_kernel, dim3((unsigned)steps), dim3(256), 0, stream, d_run, partial_waves);
         hipLaunchKernelGGL(de_advance_kernel, dim3(1), dim3(1), 0, stream, d_run, steps);
         return MCMCPP_HIP_OK;
     }
 
-    // hipGraph of `steps` ensemble steps
-    int graph_for(int steps, hipGraphExec_t* out)
+    // hipGraph of `steps` ensemble steps that start at half-step h0: where the batch boundaries fall, and which of the two
+    // batch records a boundary writes, depends on h0 mod two batches
+    int graph_for(int steps, uint64_t h0, hipGraphExec_t* out)
     {
-        const size_t key = (size_t)steps;
-        if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
-        if (!graph_cache[key])
+        const uint64_t phase = h0 % (2 * (uint64_t)batch_max);
+        const uint64_t key = (uint64_t)steps * (2 * (uint64_t)batch_max) + phase;
+        auto it = graph_cache.find(key);
+        if (it == graph_cache.end())
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            int rc = enqueue_replay(steps);
+            int rc = enqueue_replay(steps, phase);
             if (rc) return rc;
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
             HIP_TRY(hipGraphDestroy(g));
-            graph_cache[key] = ex;
+            it = graph_cache.emplace(key, ex).first;
         }
-        *out = graph_cache[key];
+        *out = it->second;
         return MCMCPP_HIP_OK;
     }
 
     int enqueue_steps(int64_t steps)
     {
+        if (!primed)
+        {
+            int rc = prime();
+            if (rc) return rc;
+        }
         int64_t left = steps;
         while (left > 0)
         {
@@ -450,15 +465,16 @@ public:
             if (graph_steps >= 1)
             {
                 hipGraphExec_t ex = nullptr;
-                int rc = graph_for(now, &ex);
+                int rc = graph_for(now, half_steps, &ex);
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
             }
             else
             {
-                int rc = enqueue_replay(now);
+                int rc = enqueue_replay(now, half_steps);
                 if (rc) return rc;
             }
+            half_steps += 2 * (uint64_t)now;
             left -= now;
         }
         HIP_TRY(hipGetLastError());
@@ -510,9 +526,19 @@ public:
         }
         if (redraws)
         {
-            DeHead h;
-            HIP_TRY(hipMemcpy(&h, d_head, sizeof h, hipMemcpyDeviceToHost));
-            *redraws = h.extra_total;  // every draw thrown away so far (bounded_rand, ind2 == ind1)
+            // every draw thrown away so far (bounded_rand, ind2 == ind1): the stream is planned ahead of the updates, so
+            // count from the record of the batch the next half-step belongs to
+            *redraws = 0;
+            if (primed)
+            {
+                std::vector<DeBatch> rec(1);
+                const uint64_t b = half_steps / (uint64_t)batch_max;
+                HIP_TRY(hipMemcpy(rec.data(), d_batch + (b & 1), sizeof(DeBatch), hipMemcpyDeviceToHost));
+                const uint64_t done = (half_steps % (uint64_t)batch_max) * (uint64_t)n;  // updates of this batch behind us
+                uint64_t shift = 0;
+                for (uint32_t e = 0; e < rec[0].events && e < (uint32_t)kDeMaxEvents && (uint64_t)rec[0].plan[e].m < done; ++e) shift = rec[0].plan[e].shift_after;
+                *redraws = rec[0].extra_base + shift;
+            }
         }
         return MCMCPP_HIP_OK;
     }
@@ -573,10 +599,9 @@ private:
     {
         if (device >= 0) (void)hipSetDevice(device);
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
-        for (hipGraphExec_t ex : graph_cache)
-            if (ex) (void)hipGraphExecDestroy(ex);
-        if (plan_stream) (void)hipStreamSynchronize(plan_stream);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_head, d_batch, d_counts, d_params, d_jump_lo, d_jump_hi, d_jump_small, d_chain, d_acc, d_recs, d_run, d_bad, d_scan_lo, d_scan_hi};
+        for (auto& kv : graph_cache)
+            if (kv.second) (void)hipGraphExecDestroy(kv.second);
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_head, d_batch, d_run, d_counts, d_params, d_tables, d_chain, d_acc, d_recs, d_bad};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         for (int k = 0; k < 2; ++k)
@@ -584,9 +609,6 @@ private:
             if (ev_t0[k]) (void)hipEventDestroy(ev_t0[k]);
             if (ev_t1[k]) (void)hipEventDestroy(ev_t1[k]);
         }
-        for (hipEvent_t e : events)
-            if (e) (void)hipEventDestroy(e);
-        if (plan_stream) (void)hipStreamDestroy(plan_stream);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
     }
 
@@ -601,6 +623,7 @@ private:
     Diag* d_diag = nullptr;
     DeHead* d_head = nullptr;
     DeBatch* d_batch = nullptr;
+    Affine128* d_tables = nullptr;  // jump_small, scan_lo, jump_lo, jump_hi, scan_hi
     uint32_t* d_counts = nullptr;
     DeBad* d_bad = nullptr;
     Affine128 *d_scan_lo = nullptr, *d_scan_hi = nullptr;
@@ -610,18 +633,17 @@ private:
     DeRunInfo* d_run = nullptr;
     DeArgs<T> args;
     int update_blocks = 0, partial_waves = 0, graph_steps = 128, replay_steps_max = 128, knob_debug = 0;
-    bool knob_overlap = true;
-    hipStream_t plan_stream = nullptr;  // the planning launches of the next batch, beside the updates of this one
-    std::vector<hipEvent_t> events;     // fork/join between the two streams (graph edges under capture)
-    std::vector<Affine128> batch_jumps; // [half-steps of a batch]: (D+3) * n * that many draws
+    int resolve_capacity = 0, scan_blocks = 0;
+    bool primed = false;    // batches 0 and 1 planned behind the last set_state
+    Affine128 batch_jump;   // (D+3) * n * batch_max draws
     bool run_touched = false;
     hipEvent_t ev_t0[2] = {nullptr, nullptr}, ev_t1[2] = {nullptr, nullptr};
-    std::vector<hipGraphExec_t> graph_cache;
+    std::unordered_map<uint64_t, hipGraphExec_t> graph_cache;
 
     Affine128 *d_jump_lo = nullptr, *d_jump_hi = nullptr, *d_jump_small = nullptr;
     size_t chain_bytes = 0, acc_count = 0;
     U128 state0, inc;
-    uint64_t threshold = 0, steps_since_reset = 0;
+    uint64_t threshold = 0, steps_since_reset = 0, half_steps = 0;
     T gamma = 0;
     double last_ms = 0.0;
     int64_t last_launches = 0;

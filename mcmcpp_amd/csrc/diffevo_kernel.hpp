@@ -10,22 +10,29 @@
 // the number of draws an update starting there throws away.  Update m of the stream (m counts updates across
 // half-steps) starts at position (D+3) m + c, c the draws thrown away before it; c changes only where a start is bad
 // (an EVENT: about one per half-step, whatever n is).  So the stream is PLANNED, a batch of up to kDeBatchMax
-// half-steps at a time, by three small launches that depend on nothing but the stream:
-//   de_scan_kernel     every stream position the batch can reach is drawn ONCE -- a lane jumps to its run of positions
-//                      through two table look-ups and steps through it -- and the bad ones go, with their E, to
-//                      one of kDeSegments lists (a counter per list on a line of its own: same-line atomics serialise);
-//   de_resolve_kernel  one workgroup holds the bad positions in LDS and walks the events: "the first bad position that
-//                      IS the start of an update behind the last event, given c" is one minimum over the workgroup;
-//                      it leaves the event list and the stream head behind the batch;
-//   de_records_kernel  one lane per update: its shift from a search in the event list, a jump to its place (three table
-//                      look-ups), its integer draws replayed, and the update's 32-byte record -- the two partners, the
-//                      engine state behind the integer draws, the logarithm of its accept draw.
+// half-steps at a time, by three roles that depend on nothing but the stream:
+//   scan     every stream position the batch can reach is drawn ONCE -- a lane jumps to its run of positions through two
+//            table look-ups and steps through it -- and the bad ones go, with their E, to one of kDeSegments lists (a
+//            counter per list on a line of its own: same-line atomics serialise);
+//   resolve  one workgroup sorts the bad positions by residue mod (D+3) in LDS and walks the events: "the first bad
+//            position that IS the start of an update behind the last event, given c" is one minimum over a wavefront
+//            among the handful of positions of one residue; it leaves the event list and the stream head behind the batch;
+//   records  one lane per update: its shift from a search in the event list, a jump to its place (three table
+//            look-ups), its integer draws replayed, and the update's 32-byte record -- the two partners, the engine
+//            state behind the integer draws, the logarithm of its accept draw.
 // The updates themselves are one launch per half-step (de_update_kernel), the stretch half-step kernel's structure:
 // first round trip the record, own row, log-posterior, counter; second round trip the two partner rows; in its shadow
 // the lanes draw their own jitters; calculator, accept in place, optional chain store, the wavefront's accepted count.
-// The host puts the planning of batch b + 1 on a second stream beside the updates of batch b (diffevo.hip); a run's
-// launches are replayed from a hipGraph; the stream head, the sticky error flags and the per-run counters travel in
-// device memory.  A batch that throws away more than kDeShiftMax draws, lists more bad positions than the resolver
+// The planning runs as launches of its own between the update launches of two batches, a batch boundary costs two of them:
+//   de_resolve_records_kernel   the resolve of batch b + 2 (one workgroup) beside the records of batch b + 1 (they are
+//                               independent: the records come from the resolve made one boundary earlier);
+//   de_scan_kernel              the scan of batch b + 3, from the stream head the resolve has just left.
+// Measured against two alternatives that hide the planning instead of adding it: on a second stream beside the
+// update launches (the cross-queue dependencies and the chip-filling scan cost more than they hide), and as extra
+// workgroups of the update launches themselves (the 128-bit integer arithmetic of scan and jitters then competes for the
+// same vector ALUs: every launch stretches by as much as the planning takes on its own).
+// A run's launches are replayed from a hipGraph; the stream head, the sticky error flags and the per-run counters travel
+// in device memory.  A batch that throws away more than kDeShiftMax draws, lists more bad positions than the resolver
 // holds, or contains an update that throws away more than kDeWindow - 2 raises an error flag the host turns into a
 // failed run: never a silently different chain.
 #pragma once
@@ -34,7 +41,7 @@
 
 namespace mcmcpp
 {
-constexpr int kDeBatchMax = 32;     // half-steps one plan covers at most
+constexpr int kDeBatchMax = 64;     // half-steps one plan covers at most
 constexpr int kDeShiftMax = 4095;   // thrown-away draws inside one batch that are followed exactly (expected: about one per half-step)
 constexpr int kDeWindow = 32;       // raw draws one update's integer part may consume (2 + up to 30 thrown away: even two
                                     // walkers per half, where every second ind2 collides, overrun once in 1e9 updates)
@@ -45,6 +52,7 @@ constexpr int kDeMaxBad = 8192;     // bad positions of a batch the resolver hol
 constexpr int kDeMaxEvents = 1024;  // events of a batch
 constexpr int kDeScanRun = 8;       // consecutive stream positions one scanning lane steps through (default)
 constexpr int kDePlanThreads = 256;
+constexpr int kDeMaxPer = 1024 + 3;  // draws per update at the largest D the kernels are built for
 
 enum : uint32_t
 {
@@ -81,8 +89,9 @@ struct DePlan
 struct alignas(64) DeBatch
 {
     U128 base;  // engine state in front of the batch's first draw
+    unsigned long long extra_base;  // draws thrown away before the batch
     uint32_t events;
-    uint32_t pad[11];
+    uint32_t pad[9];
     DePlan plan[kDeMaxEvents];
 };
 
@@ -114,7 +123,7 @@ static_assert(sizeof(DeRunInfo) == 64, "one line");
 struct DePlanArgs
 {
     DeHead* head;
-    DeBatch* batch;
+    DeBatch* batch;               // the record the resolve writes
     DeBad* bad;                   // [kDeSegments][bad_capacity]
     uint32_t* counts;             // [kDeSegments] at stride kDeCountStride
     const Affine128* scan_hi;     // [ceil(scan lanes / 256)]  scan_run*256*j draws

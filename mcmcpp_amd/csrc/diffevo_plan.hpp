@@ -1,4 +1,4 @@
-// diffevo_plan.hpp -- the planning launches of Mover::DifferentialEvolution (scheme: diffevo_kernel.hpp): scan, resolve,
+// diffevo_plan.hpp -- the stream planning of Mover::DifferentialEvolution (scheme: diffevo_kernel.hpp): scan, resolve,
 // records, and the two small launches behind a replay.  They depend on the random stream alone, not on the calculator:
 // compiled once, in diffevo.hip.
 #pragma once
@@ -10,16 +10,19 @@ namespace mcmcpp
 __device__ __forceinline__ uint32_t de_bounded(uint64_t v, int n, bool pow2) { return pow2 ? (uint32_t)(v & (uint64_t)(n - 1)) : (uint32_t)(v % (uint64_t)n); }
 
 // ---- scan: every stream position of the batch, drawn once; the bad ones listed ------------------------------------------
-__global__ void __launch_bounds__(kDePlanThreads) de_scan_kernel(const DePlanArgs a)
+// t: the scanning lane (of the whole batch)
+__device__ __forceinline__ void de_scan_lane(const DePlanArgs& a, int t)
 {
     const int n = a.n;
     const bool pow2 = (n & (n - 1)) == 0;
     const uint64_t threshold = a.threshold;
+    // (the loads first: the bounds come from the kernarg segment, which is cold)
+    const Affine128 f_lo = a.scan_lo[t & 255], f_hi = a.scan_hi[t >> 8];
+    const U128 head_state = a.head->state;
     const int positions = a.positions, run = a.scan_run;
-    const int t = (int)blockIdx.x * kDePlanThreads + (int)threadIdx.x;
     if ((long long)t * run >= positions) return;
     // the state behind run * t draws, then position after position
-    U128 s = apply(a.scan_lo[t & 255], apply(a.scan_hi[t >> 8], a.head->state));
+    U128 s = apply(f_lo, apply(f_hi, head_state));
     s = pcg_step(s, a.inc);
     uint64_t raw = pcg_output(s);
     uint32_t ind = de_bounded(raw, n, pow2);
@@ -80,46 +83,67 @@ __global__ void __launch_bounds__(kDePlanThreads) de_scan_kernel(const DePlanArg
     }
 }
 
-// ---- resolve: the events of the batch, in stream order; the stream head behind the batch -------------------------------
-__global__ void __launch_bounds__(kDePlanThreads) de_resolve_kernel(const DePlanArgs a)
+// minimum over the wavefront, in every lane (DPP inside the rows of 16, then the four rows through scalar registers)
+__device__ __forceinline__ uint32_t de_wave_min(uint32_t v)
 {
-    // a bad position p = per * q + res is the start of update q - c / per when c draws have been thrown away and
-    // res == c mod per
-    __shared__ uint32_t sh_q[kDeMaxBad];
-    __shared__ uint16_t sh_res[kDeMaxBad];
-    __shared__ uint8_t sh_e[kDeMaxBad];
-    __shared__ uint32_t sh_off[kDeSegments + 1];
-    __shared__ unsigned long long sh_min[kDePlanThreads / 64];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    v = o < v ? o : v;
+    o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xF, 0xF, false);  // row_mirror
+    v = o < v ? o : v;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
+
+// ---- resolve: the events of the batch, in stream order; the stream head behind the batch -------------------------------
+// A bad position p = per * q + res is the start of update q - c / per when c draws have been thrown away and
+// res == c mod per: the positions are kept by residue (a counting sort in LDS), so that an event looks at one residue's
+// handful of positions only.  One workgroup of `threads` lanes sorts, its first wavefront walks.
+// lds: capacity + 2 * per + 2 + kDeSegments uint32.
+__host__ __device__ inline size_t de_resolve_lds_bytes(int capacity, int per) { return sizeof(uint32_t) * ((size_t)capacity + 2 * (size_t)per + 2 + kDeSegments); }
+
+__device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* lds, int capacity, int threads)
+{
     const uint32_t per = (uint32_t)a.dims + 3u;
+    uint32_t* const sh_key = lds;                  // [capacity]  q << 8 | E, residue after residue
+    uint32_t* const sh_start = sh_key + capacity;  // [per + 1]   where each residue's keys begin
+    uint32_t* const sh_fill = sh_start + per + 1;  // [per]
+    uint32_t* const sh_off = sh_fill + per;        // [kDeSegments + 1]
+    static_assert(kDeSegments == 64, "one list per lane of the first wavefront");
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const DeHead head = *a.head;
     uint32_t err = 0;
 
-    if (tid < kDeSegments)
+    if (wave == 0)
     {
-        const uint32_t listed = a.counts[(size_t)tid * kDeCountStride];
-        sh_off[tid + 1] = listed < (uint32_t)a.bad_capacity ? listed : (uint32_t)a.bad_capacity;
-    }
-    __syncthreads();
-    if (tid == 0)
-    {
-        uint32_t sum = 0;
-        sh_off[0] = 0;
-        for (int g = 0; g < kDeSegments; ++g)
+        // the lists end to end: an inclusive scan of their lengths over the wavefront
+        const uint32_t listed = a.counts[(size_t)lane * kDeCountStride];
+        uint32_t sum = listed < (uint32_t)a.bad_capacity ? listed : (uint32_t)a.bad_capacity;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
         {
-            sum += sh_off[g + 1];
-            sh_off[g + 1] = sum;
+            const uint32_t up = __shfl_up(sum, off);
+            if (lane >= off) sum += up;
         }
+        sh_off[lane + 1] = sum;
+        if (lane == 0) sh_off[0] = 0;
+        a.counts[(size_t)lane * kDeCountStride] = 0;  // for the next batch's scan
     }
+    for (uint32_t r = (uint32_t)tid; r < per; r += (uint32_t)threads) sh_fill[r] = 0;
     __syncthreads();
     int total = (int)sh_off[kDeSegments];
-    if (total > kDeMaxBad)
+    if (total > capacity)
     {
-        err |= kDeErrCand;
-        total = kDeMaxBad;
+        err |= kDeErrCand;  // (positions beyond what the LDS holds are not looked at: a failed run)
+        total = capacity;
     }
-    for (int idx = tid; idx < total; idx += kDePlanThreads)
-    {
+    auto entry = [&](int idx) -> DeBad {
         int lo = 0, hi = kDeSegments - 1;  // the list idx falls into: the last one whose offset is <= idx
         while (lo < hi)
         {
@@ -129,107 +153,163 @@ __global__ void __launch_bounds__(kDePlanThreads) de_resolve_kernel(const DePlan
             else
                 hi = mid - 1;
         }
-        const DeBad b = a.bad[(size_t)lo * a.bad_capacity + ((uint32_t)idx - sh_off[lo])];
-        const uint32_t q = b.p / per;
-        sh_q[idx] = q;
-        sh_res[idx] = (uint16_t)(b.p - q * per);
-        sh_e[idx] = (uint8_t)b.e;
+        return a.bad[(size_t)lo * a.bad_capacity + ((uint32_t)idx - sh_off[lo])];
+    };
+    // Eight positions per lane at a time (their loads leave together), kept in registers between the two passes of the
+    // counting sort when that is all there is (the usual case).
+    DeBad held[8];
+    const bool once = total <= 8 * threads;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (tid + u * threads < total) held[u] = entry(tid + u * threads);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (tid + u * threads < total) atomicAdd(&sh_fill[held[u].p % per], 1u);
+    for (int idx = tid + 8 * threads; idx < total; idx += threads) atomicAdd(&sh_fill[entry(idx).p % per], 1u);
+    __syncthreads();
+    if (wave == 0)
+    {
+        uint32_t carry = 0;
+        for (uint32_t r0 = 0; r0 < per; r0 += 64)
+        {
+            const uint32_t r = r0 + (uint32_t)lane;
+            const uint32_t mine = r < per ? sh_fill[r] : 0u;
+            uint32_t sum = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1)
+            {
+                const uint32_t up = __shfl_up(sum, off);
+                if (lane >= off) sum += up;
+            }
+            if (r < per)
+            {
+                sh_start[r] = carry + sum - mine;
+                sh_fill[r] = 0;
+            }
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)sum, 63);
+        }
+        if (lane == 0) sh_start[per] = carry;
     }
     __syncthreads();
+    auto place = [&](const DeBad& b) {
+        const uint32_t q = b.p / per, res = b.p - q * per;
+        sh_key[sh_start[res] + atomicAdd(&sh_fill[res], 1u)] = (q << 8) | (b.e & 0xFFu);
+    };
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+        if (tid + u * threads < total) place(held[u]);
+    if (!once)
+        for (int idx = tid + 8 * threads; idx < total; idx += threads) place(entry(idx));
+    __syncthreads();
+    if (wave != 0) return;
 
-    // The walk, in stream order: with c draws thrown away so far, update m starts at per * m + c; the next event is the
-    // first bad position that IS the start of an update behind the last event's.  One minimum per event.
-    uint32_t c = 0, events = 0;
-    long long m_last = -1;  // (a position inside the draws of the update whose start was the last event is no start)
+    // The walk, by one wavefront: with c draws thrown away so far, update m starts at per * m + c; the next event is the
+    // first bad position that IS the start of an update behind the last event's.  One minimum over the wavefront per
+    // event (key: update index, then E; the updates of a batch number fewer than 2^23).
+    DeBatch* const out = a.batch;
+    uint32_t c = 0, cq = 0, cr = 0, events = 0;  // c = per * cq + cr
+    int m_last = -1;  // (a position inside the draws of the update whose start was the last event is no start)
     while (true)
     {
-        const uint32_t cq = c / per, cr = c - cq * per;
-        unsigned long long best = ~0ULL;
-        for (int idx = tid; idx < total; idx += kDePlanThreads)
+        uint32_t best = ~0u;
+        const int begin = (int)sh_start[cr], end = (int)sh_start[cr + 1];
+        for (int i = begin + lane; i < end; i += 64)
         {
-            if ((uint32_t)sh_res[idx] != cr) continue;
-            const long long m = (long long)sh_q[idx] - (long long)cq;
-            if (m > m_last && m < (long long)a.updates)
+            const uint32_t key = sh_key[i];
+            const int m = (int)(key >> 8) - (int)cq;
+            if (m > m_last && m < a.updates)
             {
-                const unsigned long long key = ((unsigned long long)m << 8) | (unsigned long long)sh_e[idx];
-                best = key < best ? key : best;
+                const uint32_t mine = ((uint32_t)m << 8) | (key & 0xFFu);
+                best = mine < best ? mine : best;
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-        {
-            const unsigned long long other = __shfl_xor(best, off);
-            best = other < best ? other : best;
-        }
-        __syncthreads();  // (the previous round's sh_min has been read by everyone)
-        if (lane == 0) sh_min[wave] = best;
-        __syncthreads();
-        best = sh_min[0];
-#pragma unroll
-        for (int wv = 1; wv < kDePlanThreads / 64; ++wv) best = sh_min[wv] < best ? sh_min[wv] : best;
-        if (best == ~0ULL) break;
-        uint32_t own = (uint32_t)(best & 0xFFu);
-        const uint32_t m = (uint32_t)(best >> 8);
+        best = de_wave_min(best);
+        if (best == ~0u) break;
+        uint32_t own = best & 0xFFu;
+        const uint32_t m = best >> 8;
         if (own == (uint32_t)kDeOverrun)
         {
             err |= kDeErrWindow;
             own = 0;
         }
-        c += own;
-        if (c > (uint32_t)kDeShiftMax)
+        if (c + own > (uint32_t)kDeShiftMax)
         {
             err |= kDeErrShift;
-            c = (uint32_t)kDeShiftMax;
+            own = (uint32_t)kDeShiftMax - c;
+        }
+        c += own;
+        cr += own;
+        while (cr >= per)
+        {
+            cr -= per;
+            ++cq;
         }
         if (events < (uint32_t)kDeMaxEvents)
         {
-            if (tid == 0)
+            if (lane == 0)
             {
-                a.batch->plan[events].m = m;
-                a.batch->plan[events].shift_after = c;
+                out->plan[events].m = m;
+                out->plan[events].shift_after = c;
             }
             ++events;
         }
         else
             err |= kDeErrCand;
-        m_last = (long long)m;
+        m_last = (int)m;
     }
-    if (tid == 0)
+    if (lane == 0)
     {
-        a.batch->base = head.state;
-        a.batch->events = events;
+        out->base = head.state;
+        out->extra_base = head.extra_total;
+        out->events = events;
         // hand the stream on
         a.head->state = apply(a.jump_small[c], apply(a.batch_jump, head.state));
         a.head->extra_total = head.extra_total + (unsigned long long)c;
         if (err) atomicOr(&a.head->error, err);
     }
-    if (tid < kDeSegments) a.counts[(size_t)tid * kDeCountStride] = 0;  // for the next batch's scan
 }
 
 // ---- records: one lane per update of the batch --------------------------------------------------------------------------
+// One workgroup of `threads` lanes makes the records of updates [first, first + threads) of the batch.
+// sh_plan: LDS for the batch's events (kDeMaxEvents entries).
 template <class T>
-__global__ void __launch_bounds__(kDePlanThreads) de_records_kernel(const DePlanArgs a, DeRec<T>* recs)
+__device__ __forceinline__ void de_records_block(const DePlanArgs& a, const DeBatch* batch, DeRec<T>* recs, DePlan* sh_plan, int first, int threads)
 {
-    __shared__ DePlan sh_plan[kDeMaxEvents];
     const int n = a.n, dims = a.dims;
-    const int plan_count = (int)a.batch->events;
-    const U128 base = a.batch->base;
-    for (int j = (int)threadIdx.x; j < plan_count; j += kDePlanThreads) sh_plan[j] = a.batch->plan[j];
+    const int m = first + (int)threadIdx.x;
+    const int mm = m < a.updates ? m : a.updates - 1;
+    // first round trip: the batch record's head and its first events (one per lane, whether they exist or not: waiting
+    // for the count first would be a round trip of its own), this update's two table entries, the jump to the accept draw
+    const DePlan early = batch->plan[threadIdx.x < (unsigned)kDeMaxEvents ? threadIdx.x : 0];
+    const Affine128 j_hi = a.jump_hi[mm >> 8], j_lo = a.jump_lo[mm & 255], j_exp = a.jump_small[dims];
+    const int plan_count = (int)batch->events;
+    const U128 base = batch->base;
+    if ((int)threadIdx.x < plan_count) sh_plan[threadIdx.x] = early;
+    for (int j = (int)threadIdx.x + threads; j < plan_count; j += threads) sh_plan[j] = batch->plan[j];
     __syncthreads();
-    const int m = (int)blockIdx.x * kDePlanThreads + (int)threadIdx.x;
     if (m >= a.updates) return;
     // this update's place in the stream: the last event in front of it says how late it starts
-    int lo = 0, hi = plan_count;  // first entry with m' >= m
-    while (lo < hi)
+    int lo = 0;  // first entry with m' >= m
+    if (plan_count <= 64)
     {
-        const int mid = (lo + hi) >> 1;
-        if ((int)sh_plan[mid].m < m)
-            lo = mid + 1;
-        else
-            hi = mid;
+        // (the usual case: a count over all events -- independent LDS reads -- instead of a chain of dependent ones)
+        for (int j = 0; j < plan_count; ++j) lo += (int)sh_plan[j].m < m ? 1 : 0;
+    }
+    else
+    {
+        int hi = plan_count;
+        while (lo < hi)
+        {
+            const int mid = (lo + hi) >> 1;
+            if ((int)sh_plan[mid].m < m)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
     }
     const int shift = lo > 0 ? (int)sh_plan[lo - 1].shift_after : 0;
-    U128 s = apply(a.jump_small[shift], apply(a.jump_lo[m & 255], apply(a.jump_hi[m >> 8], base)));
+    const Affine128 j_shift = a.jump_small[shift];  // (second round trip, beside the two multiplications in front of it)
+    U128 s = apply(j_shift, apply(j_lo, apply(j_hi, base)));
     // ind1, ind2 (DifferentialEvolution.h:83-87), thrown-away draws included; the plan bounds the loops
     const bool pow2 = (n & (n - 1)) == 0;
     uint64_t v;
@@ -251,13 +331,34 @@ __global__ void __launch_bounds__(kDePlanThreads) de_records_kernel(const DePlan
         ind2 = de_bounded(v, n, pow2);
     } while (ind2 == ind1 && --budget > 0);
     // the exponential (draw D behind the integer draws and the D jitters): MultiSampler.h:80
-    const U128 se = pcg_step(apply(a.jump_small[dims], s), a.inc);
+    const U128 se = pcg_step(apply(j_exp, s), a.inc);
     DeRec<T> out;
     out.s = s;
     out.neg_exp = dev_log((T)1 - canonical(pcg_output(se), T()));  // -(-log(1 - u)/1)
     out.ind1 = ind1;
     out.ind2 = ind2;
     recs[m] = out;
+}
+
+// ---- the launches ------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kDePlanThreads) de_scan_kernel(const DePlanArgs a)
+{
+    de_scan_lane(a, (int)blockIdx.x * kDePlanThreads + (int)threadIdx.x);
+}
+
+// workgroup 0 resolves batch a.batch (if resolve != 0); the others make the records of batch rec_batch into recs
+// (record_blocks of them; the two are independent: the records belong to the batch BEFORE the one being resolved)
+template <class T>
+__global__ void __launch_bounds__(kDePlanThreads) de_resolve_records_kernel(const DePlanArgs a, int resolve, int capacity, const DeBatch* rec_batch, DeRec<T>* recs)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (resolve != 0 && blockIdx.x == 0)
+    {
+        de_resolve_block(a, reinterpret_cast<uint32_t*>(smem), capacity, kDePlanThreads);
+        return;
+    }
+    const int rb = (int)blockIdx.x - (resolve != 0 ? 1 : 0);
+    de_records_block<T>(a, rec_batch, recs, reinterpret_cast<DePlan*>(smem), rb * kDePlanThreads, kDePlanThreads);
 }
 
 // ---- behind a replay of `steps` ensemble steps: accepted proposals per step, then the run record moves on ---------------

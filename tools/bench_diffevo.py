@@ -48,7 +48,7 @@ def main():
     achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
     line = "differential evolution %d x %d dense Gaussian: device %.3e walker-steps/s (%.2f us per ensemble step by the wall clock incl. the " \
            "stored steps' download; %.2f us per launch = half-step by HIP events, 2 launches per step), acceptance %.3f, " \
-           "%d draws thrown away in %d half-steps; roofline: %.0f GB/s algorithmic = %.3f of 8000 (de_step_kernel, %d B per update)" \
+           "%d draws thrown away in %d half-steps; roofline: %.0f GB/s algorithmic = %.3f of 8000 (de_update_kernel + the planning launches, %d B per update)" \
            % (W, D, W * done / dev, dev / done * 1e6, us_per_launch, acc.sum() / (W * done), c["redraws"], 2 * (done + 50), achieved,
               achieved / 8000.0, (4 * D + 2) * 8)
     cpu_steps = max(1, min(30, (30 * 16384) // W))
