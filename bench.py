@@ -21,7 +21,8 @@ The JSON line also carries
                 oracle/Makefile) or the oracle ("port") timed on this host's cores on a bounded sample of the same
                 workload (rank 0, N = 1 only)
   secondary     (N = 1) the other single-GPU configurations of BASELINE.json, each with its own roofline object:
-                C3 (65 536 x 32 Rosenbrock) and config 5's ensemble (131 072 x 64) on one GPU
+                C3 (65 536 x 32 Rosenbrock), config 5's ensemble (131 072 x 64) and config 4's eight chains on one GPU,
+                and C2's target under Mover::DifferentialEvolution (SURVEY 8f row f3)
 `--mode split` is BASELINE config 5 proper: one ensemble split over the ranks, launches and RCCL exchanges enqueued by
 libmcmcpp_hip.so itself (mcmcpp_hip_config.comm_*).
 """
@@ -125,10 +126,11 @@ def counter_traffic(kernel):
     return None, None
 
 
-def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0):
+def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0, rows_read=2):
     """(2D+1)*8 read + (D+1)*8 written per walker update (+ D*8 when the step is stored), fp64, times the
-    walker updates one launch performs, over the average launch duration (HIP events on the launch stream)."""
-    bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
+    walker updates one launch performs, over the average launch duration (HIP events on the launch stream).
+    rows_read = 3: Mover::DifferentialEvolution, whose update reads two partner rows."""
+    bytes_per_update = (rows_read * D + 1) * 8 + (D + 1) * 8
     updates_per_launch = walker_steps / launches
     bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * 8)
     us_per_launch = gpu_ms * 1e3 / launches
@@ -138,10 +140,13 @@ def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch}
 
 
-def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1):
+def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1, mover=None):
     """One of the other single-GPU configurations: runs of `batch` ensemble steps (nothing stored) for about `seconds`,
     with its roofline.  chains > 1: that many independent ensembles (seeds 0, 1, ...) stepped by the same launches."""
-    s = capi.HipSampler(W, D, calc, params, seed=0, device=device, num_chains=chains)
+    if mover is None:
+        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, num_chains=chains)
+    else:
+        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, mover=mover)
     pos = np.stack([workloads.init_positions(W, D, salt=k) for k in range(chains)]) if chains > 1 else workloads.init_positions(W, D, salt=0)
     s.set_state(pos, s.calc_logp(pos))
     s.run(1, interval=batch, save_chain=False)
@@ -160,7 +165,7 @@ def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, 
     s.close()
     return {"workload": name, "walkers": W, "dims": D, "chains": chains, "value": ws / dt, "unit": "walker-steps/s",
             "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws,
-            "roofline": roofline_of(W, D, ws, launches, gpu_ms, kernel)}
+            "roofline": roofline_of(W, D, ws, launches, gpu_ms, kernel, rows_read=3 if mover is not None else 2)}
 
 
 def bench_split(args, rank, local_rank, world, dist, torch, capi):
@@ -428,6 +433,11 @@ def main():
                                  "Gaussian, StretchMove, fp64, stepped by the same launches (mcmcpp_hip_config.num_chains = 8); runs of 2000 "
                                  "ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
                                  "stretch_full_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>", 2000, chains=8),
+                secondary_config(capi, workloads, local_rank, "C2's target under the other ensemble mover (SURVEY 8f row f3): 16384 walkers x 32 dims, "
+                                 "correlated Gaussian, Mover::DifferentialEvolution, fp64; runs of 2000 ensemble steps, nothing stored; the launch "
+                                 "time includes the stream-planning launches", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
+                                 "de_update_kernel<double, DenseGaussianFn, EPL=2, LPW=16> (+ de_scan_kernel, de_resolve_records_kernel)", 2000,
+                                 mover=capi.MOVER_DIFFERENTIAL_EVOLUTION),
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)

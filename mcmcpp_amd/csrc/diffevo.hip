@@ -414,10 +414,11 @@ public:
             const int j = (int)(h % (uint64_t)batch_max);
             if (j == 0 && knob_debug != 1)
             {
-                launch_resolve_records((long long)b + 1, (long long)b);
+                // (timing diagnostics 3 / 4: the boundary without its records / without its resolve)
+                launch_resolve_records(knob_debug == 4 ? -1 : (long long)b + 1, knob_debug == 3 ? -1 : (long long)b);
                 launch_scan();
             }
-            if (knob_debug == 2) continue;
+            if (knob_debug >= 2) continue;
             l.recs = d_recs + (size_t)j * (size_t)n;
             l.color = (int)(h & 1);
             l.step = i >> 1;
@@ -437,6 +438,14 @@ public:
         auto it = graph_cache.find(key);
         if (it == graph_cache.end())
         {
+            if (graph_cache.size() >= 64)
+            {
+                // (runs of ever-changing lengths: the graphs still queued have been launched, not destroyed under them)
+                HIP_TRY(hipStreamSynchronize(stream));
+                for (auto& kv : graph_cache)
+                    if (kv.second) (void)hipGraphExecDestroy(kv.second);
+                graph_cache.clear();
+            }
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
             int rc = enqueue_replay(steps, phase);

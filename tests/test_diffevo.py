@@ -125,6 +125,9 @@ def test_device_differential_evolution_resumes_across_calls():
     (600, 257, po.CALC_ISO_GAUSSIAN, None, po.F64, 8, 1), (1026, 32, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 40, 1),
     (64, 7, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F32, 200, 1), (4096, 16, po.CALC_ISO_GAUSSIAN, None, po.F32, 20, 5),
     (4100, 8, po.CALC_ISO_GAUSSIAN, None, po.F64, 30, 1),
+    # BASELINE's larger ensembles (several planning batches each) and the widest walker the kernels are built for
+    (65536, 32, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 70, 35), (131072, 64, po.CALC_ISO_GAUSSIAN, None, po.F64, 3, 1),
+    (2200, 1024, po.CALC_ISO_GAUSSIAN, None, po.F64, 6, 1),
 ])
 def test_device_differential_evolution_matches_the_oracle(W, D, calc, params, dt, steps, interval):
     pos = po.init_positions(dt, W, D, salt=6)
@@ -143,6 +146,26 @@ def test_device_differential_evolution_matches_the_oracle(W, D, calc, params, dt
     assert c["redraws"] == orc.redraws and c["ensemble_steps"] == steps * interval
     if dt == po.F64:  # (fp32 decisions within a few ulp of flipping do occur at this count; chain equality above is the test)
         assert c["near_ties"] == 0 and orc.near_ties == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,scan_run", [(1, 8), (3, 1), (7, 5), (64, 32)])
+def test_device_differential_evolution_planning_batches_of_any_length(monkeypatch, batch, scan_run):
+    # the planner's batch length and scan run are free parameters of the device path: the chain must not depend on them
+    monkeypatch.setenv("MCMCPP_HIP_DE_BATCH", str(batch))
+    monkeypatch.setenv("MCMCPP_HIP_DE_SCAN_RUN", str(scan_run))
+    W, D, steps = 22, 2, 300
+    pos = po.init_positions(po.F64, W, D, salt=3)
+    orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=5, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
+    lp = orc.logp(pos)
+    orc.set_state(pos, lp)
+    want_chain, want_acc = orc.run(steps, 1)
+    s = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=5, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION)
+    s.set_state(pos, lp)
+    got = [s.run(k, 1) for k in (1, 2, 97, 200)]  # (runs that begin and end anywhere inside a batch)
+    np.testing.assert_array_equal(np.concatenate([g[0] for g in got]), want_chain)
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got]), want_acc)
+    assert s.counters()["redraws"] == orc.redraws
 
 
 @pytest.mark.gpu
