@@ -33,6 +33,7 @@
 namespace
 {
 constexpr int kAcThreads = 256;
+constexpr int kXcds = 8;  // MI355X: 8 XCDs x 32 CUs, workgroups dispatched to them round robin
 constexpr size_t kAcLdsBytes = 64 << 10;
 
 __device__ __forceinline__ unsigned ac_bit_reverse(unsigned x, int lg) { return __builtin_bitreverse32(x) >> (32 - lg); }
@@ -131,11 +132,18 @@ __device__ __forceinline__ void ac_fft_pass(T* re, T* im, int lg, const T* __res
 // acov[series][0..n): normalised autocovariance function of series (first_sel + series / D, series % D)
 template <class T, bool LDS>
 __global__ void __launch_bounds__(kAcThreads)
-ac_autocov_kernel(const T* steps, int n, long long step_elems, const int* walker_idx, int first_sel, int D, const T* avg, const T* __restrict__ tw, int lg, T* scratch, T* acov)
+ac_autocov_kernel(const T* steps, int n, long long step_elems, const int* walker_idx, int first_sel, int D, const T* avg, const T* __restrict__ tw, int lg, T* scratch, T* acov,
+                  int series_count)
 {
     extern __shared__ __align__(16) unsigned char ac_smem[];
     const int fft = 1 << lg;
-    const int series = blockIdx.x;
+    // Workgroups go to the eight XCDs round robin, and each XCD has an L2 of its own.  A series is read with a stride of
+    // a whole stored step (the chain is step-major), eight bytes out of every line, and the other words of those lines
+    // belong to the NEIGHBOURING series: so neighbouring series go to the same XCD (XCD x takes series [x, x + 1) * count / 8
+    // in order), where the workgroups resident together share the lines in L2 instead of each fetching them from memory.
+    const int per_xcd = (series_count + kXcds - 1) / kXcds;
+    const int series = (int)(blockIdx.x % kXcds) * per_xcd + (int)(blockIdx.x / kXcds);
+    if (series >= series_count) return;  // (the grid is whole rounds over the XCDs)
     const int sel = first_sel + series / D, p = series % D;
     T* re = LDS ? reinterpret_cast<T*>(ac_smem) : scratch + (size_t)series * 2 * fft;
     T* im = re + fft;
@@ -357,12 +365,13 @@ int autocorr_times(const void* const* steps, const T* device_steps, int64_t n_st
     for (int first = 0; first < use; first += chunk)
     {
         const int cw = use - first < chunk ? use - first : chunk;
+        const unsigned ac_grid = (unsigned)(((cw * D + kXcds - 1) / kXcds) * kXcds);  // (whole rounds over the XCDs)
         if (lds)
-            hipLaunchKernelGGL((ac_autocov_kernel<T, true>), dim3((unsigned)cw * D), dim3(kAcThreads), sizeof(T) * 2 * (size_t)fft, dev.stream, d_steps, n,
-                               (long long)step_elems, d_idx, first, D, d_avg, d_tw, lg, d_scratch, d_acov);
+            hipLaunchKernelGGL((ac_autocov_kernel<T, true>), dim3(ac_grid), dim3(kAcThreads), sizeof(T) * 2 * (size_t)fft, dev.stream, d_steps, n,
+                               (long long)step_elems, d_idx, first, D, d_avg, d_tw, lg, d_scratch, d_acov, cw * D);
         else
-            hipLaunchKernelGGL((ac_autocov_kernel<T, false>), dim3((unsigned)cw * D), dim3(kAcThreads), 0, dev.stream, d_steps, n, (long long)step_elems, d_idx,
-                               first, D, d_avg, d_tw, lg, d_scratch, d_acov);
+            hipLaunchKernelGGL((ac_autocov_kernel<T, false>), dim3(ac_grid), dim3(kAcThreads), 0, dev.stream, d_steps, n, (long long)step_elems, d_idx,
+                               first, D, d_avg, d_tw, lg, d_scratch, d_acov, cw * D);
         hipLaunchKernelGGL(ac_accumulate_kernel<T>, dim3((unsigned)(((long long)D * n + kAcThreads - 1) / kAcThreads)), dim3(kAcThreads), 0, dev.stream, d_acov, n,
                            D, cw, d_sum, d_comp);
     }
