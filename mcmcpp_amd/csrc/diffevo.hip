@@ -83,8 +83,8 @@ public:
         const unsigned per = (unsigned)D + 3u;
         {
             long long b = batch_max < 1 ? 1 : (batch_max > kDeBatchMax ? kDeBatchMax : batch_max);
-            const long long by_positions = ((1LL << 30) - kDeShiftMax - 1) / ((long long)per * n);
-            const long long by_lists = (kDeMaxBad * 5LL / 8 - (kDeShiftMax + 1) / n) / per;
+            const long long by_positions = ((1LL << 30) - 2 * (kDeShiftMax + 1)) / ((long long)per * n);
+            const long long by_lists = (kDeMaxBad * 5LL / 8 - 2 * (kDeShiftMax + 1) / n) / per;
             const long long by_records = (8LL << 20) / n;
             b = b < by_positions ? b : by_positions;
             b = b < by_lists ? b : by_lists;
@@ -95,7 +95,7 @@ public:
             batch_max = (int)b;
         }
         const size_t updates_max = (size_t)batch_max * n;
-        positions_max = (long long)per * (long long)(updates_max - 1) + kDeShiftMax + 1;
+        positions_max = (long long)per * (long long)(updates_max - 1) + 2 * (kDeShiftMax + 1);  // (what a scan looks at)
         // one stream position in n is bad: a batch lists about (D + 3) of them per half-step (and as many again as the
         // kDeShiftMax positions behind its end hold, which matters for tiny ensembles), spread evenly over the lists
         {
@@ -110,10 +110,10 @@ public:
         HIP_TRY(hipMalloc(&d_logp, sizeof(T) * (size_t)W));
         HIP_TRY(hipMalloc(&d_nacc, sizeof(uint32_t) * (size_t)W));
         HIP_TRY(hipMalloc(&d_diag, sizeof(Diag)));
-        HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * kDeSegments * kDeCountStride));
-        HIP_TRY(hipMemset(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride));
-        HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
-        HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * kDeSegments * (size_t)bad_capacity));
+        HIP_TRY(hipMalloc(&d_counts, sizeof(uint32_t) * 2 * kDeSegments * kDeCountStride));  // two sets of lists (launch_boundary)
+        HIP_TRY(hipMemset(d_counts, 0, sizeof(uint32_t) * 2 * kDeSegments * kDeCountStride));
+        HIP_TRY(hipMalloc(&d_bad, sizeof(DeBad) * 2 * kDeSegments * (size_t)bad_capacity));
+        HIP_TRY(hipMemset(d_bad, 0, sizeof(DeBad) * 2 * kDeSegments * (size_t)bad_capacity));
         HIP_TRY(hipMalloc(&d_recs, sizeof(DeRec<T>) * updates_max));  // the records of the batch being stepped through
         for (int k = 0; k < 2; ++k)
         {
@@ -212,8 +212,10 @@ public:
         DeHead h;
         std::memset(&h, 0, sizeof h);
         h.state = state0;
+        h.provisional[0] = state0;  // (batches 0 and 1 are scanned before anything has been resolved)
+        h.provisional[1] = apply(batch_jump, state0);
         HIP_TRY(hipMemcpyAsync(d_head, &h, sizeof h, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * kDeSegments * kDeCountStride, stream));
+        HIP_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * 2 * kDeSegments * kDeCountStride, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         steps_since_reset = 0;
         half_steps = 0;
@@ -335,15 +337,14 @@ public:
         return MCMCPP_HIP_OK;
     }
 
-    // what every planning launch of this handle shares (batches are always batch_max half-steps long)
-    DePlanArgs plan_args() const
+    // The boundary launch in front of a batch: the resolve of batch `resolve_batch` (scanned before), the records of batch
+    // `record_batch` (resolved before) and the scan of batch `scan_batch`; any of them < 0: not in this launch (priming).
+    void launch_boundary(long long resolve_batch, long long record_batch, long long scan_batch)
     {
         const unsigned per = (unsigned)D + 3u;
         DePlanArgs p;
         std::memset(&p, 0, sizeof p);
         p.head = d_head;
-        p.bad = d_bad;
-        p.counts = d_counts;
         p.scan_hi = d_scan_hi;
         p.scan_lo = d_scan_lo;
         p.jump_hi = d_jump_hi;
@@ -356,46 +357,43 @@ public:
         p.dims = D;
         p.updates = n * batch_max;
         p.positions = (int)((long long)per * (long long)(p.updates - 1) + kDeShiftMax + 1);
+        p.scan_positions = p.positions + kDeShiftMax + 1;
         p.scan_run = scan_run;
-        p.seg_len = (p.positions + kDeSegments - 1) / kDeSegments;
+        p.seg_len = (p.scan_positions + kDeSegments - 1) / kDeSegments;
         p.bad_capacity = bad_capacity;
-        return p;
-    }
-
-    // the scan of the batch the stream head stands in front of
-    void launch_scan() { hipLaunchKernelGGL(de_scan_kernel, dim3((unsigned)scan_blocks), dim3(kDePlanThreads), 0, stream, plan_args()); }
-
-    // the resolve of batch `resolve_batch` (scanned before; < 0: none) beside the records of batch `record_batch` (resolved
-    // before; < 0: none), one launch
-    void launch_resolve_records(long long resolve_batch, long long record_batch)
-    {
-        DePlanArgs p = plan_args();
+        // two sets of lists: batch b is scanned into set b & 1 (its resolve runs beside the scan of batch b + 1)
+        const long long sb = scan_batch >= 0 ? scan_batch : resolve_batch + 1;
+        p.scan_parity = (int)(sb & 1);
+        p.bad = d_bad + (size_t)(sb & 1) * kDeSegments * (size_t)bad_capacity;
+        p.counts = d_counts + (size_t)(sb & 1) * kDeSegments * kDeCountStride;
+        p.resolve_bad = d_bad + (size_t)((sb + 1) & 1) * kDeSegments * (size_t)bad_capacity;
+        p.resolve_counts = d_counts + (size_t)((sb + 1) & 1) * kDeSegments * kDeCountStride;
         p.batch = d_batch + (resolve_batch >= 0 ? (resolve_batch & 1) : 0);
+        const int resolve = resolve_batch >= 0 ? 1 : 0;
         const int record_blocks = record_batch >= 0 ? (p.updates + kDePlanThreads - 1) / kDePlanThreads : 0;
+        const int scan_now = scan_batch >= 0 ? scan_blocks : 0;
         size_t lds = record_blocks ? sizeof(DePlan) * kDeMaxEvents : 0;
-        const size_t need = resolve_batch >= 0 ? de_resolve_lds_bytes(resolve_capacity, D + 3) : 0;
+        const size_t need = resolve ? de_resolve_lds_bytes(resolve_capacity, D + 3) : 0;
         lds = need > lds ? need : lds;
-        hipLaunchKernelGGL((de_resolve_records_kernel<T>), dim3((unsigned)(record_blocks + (resolve_batch >= 0 ? 1 : 0))), dim3(kDePlanThreads), lds, stream, p,
-                           resolve_batch >= 0 ? 1 : 0, resolve_capacity, d_batch + (record_batch >= 0 ? (record_batch & 1) : 0), d_recs);
+        hipLaunchKernelGGL((de_boundary_kernel<T>), dim3((unsigned)(resolve + record_blocks + scan_now)), dim3(kDePlanThreads), lds, stream, p, resolve, resolve_capacity,
+                           record_blocks, d_batch + (record_batch >= 0 ? (record_batch & 1) : 0), d_recs);
     }
 
     // Behind a set_state: batch 0 scanned and resolved, batch 1 scanned -- what the boundary in front of a batch finds
     // (see enqueue_replay).
     int prime()
     {
-        launch_scan();
-        launch_resolve_records(0, -1);
-        launch_scan();
+        launch_boundary(-1, -1, 0);
+        launch_boundary(0, -1, 1);
         HIP_TRY(hipGetLastError());
         primed = true;
         return MCMCPP_HIP_OK;
     }
 
     // `steps` ensemble steps (at most replay_steps_max) from half-step h0 (counted from the set_state) on the launch stream:
-    // one update launch per half-step; in front of the first half-step of batch b the boundary's two planning launches --
-    // the resolve of batch b + 1 (scanned at the boundary before) beside the records of batch b (resolved at the boundary
-    // before), then the scan of batch b + 2 from the stream head that resolve has left.  Behind the steps: the accepted
-    // counts and the run record.
+    // one update launch per half-step; in front of the first half-step of batch b the boundary launch -- the resolve of
+    // batch b + 1 (scanned at the boundary before), the records of batch b (resolved at the boundary before) and the scan
+    // of batch b + 2.  Behind the steps: the accepted counts and the run record.
     int enqueue_replay(int steps, uint64_t h0)
     {
         typename LaunchTable<T>::DeLaunch l;
@@ -414,9 +412,8 @@ public:
             const int j = (int)(h % (uint64_t)batch_max);
             if (j == 0 && knob_debug != 1)
             {
-                // (timing diagnostics 3 / 4: the boundary without its records / without its resolve)
-                launch_resolve_records(knob_debug == 4 ? -1 : (long long)b + 1, knob_debug == 3 ? -1 : (long long)b);
-                launch_scan();
+                // (timing diagnostics 3 / 4 / 5: the boundary without its records / without its resolve / without its scan)
+                launch_boundary(knob_debug == 4 ? -1 : (long long)b + 1, knob_debug == 3 ? -1 : (long long)b, knob_debug == 5 ? -1 : (long long)b + 2);
             }
             if (knob_debug >= 2) continue;
             l.recs = d_recs + (size_t)j * (size_t)n;

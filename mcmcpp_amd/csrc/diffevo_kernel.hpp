@@ -23,10 +23,12 @@
 // The updates themselves are one launch per half-step (de_update_kernel), the stretch half-step kernel's structure:
 // first round trip the record, own row, log-posterior, counter; second round trip the two partner rows; in its shadow
 // the lanes draw their own jitters; calculator, accept in place, optional chain store, the wavefront's accepted count.
-// The planning runs as launches of its own between the update launches of two batches, a batch boundary costs two of them:
-//   de_resolve_records_kernel   the resolve of batch b + 2 (one workgroup) beside the records of batch b + 1 (they are
-//                               independent: the records come from the resolve made one boundary earlier);
-//   de_scan_kernel              the scan of batch b + 3, from the stream head the resolve has just left.
+// The planning runs as ONE launch of its own between the update launches of two batches:
+//   de_boundary_kernel   in front of batch b: the resolve of batch b + 1 (one workgroup), the records of batch b (from the
+//                        resolve made one boundary earlier) and the scan of batch b + 2, all independent of each other --
+//                        the scan does not wait for the resolve to say where batch b + 2 begins: it starts from where it
+//                        would begin had batch b + 1 thrown no draws away (DeHead::provisional) and looks kDeShiftMax + 1
+//                        positions further; the resolve of b + 2 subtracts what b + 1 did throw away.
 // Measured against two alternatives that hide the planning instead of adding it: on a second stream beside the
 // update launches (the cross-queue dependencies and the chip-filling scan cost more than they hide), and as extra
 // workgroups of the update launches themselves (the 128-bit integer arithmetic of scan and jitters then competes for the
@@ -64,10 +66,13 @@ enum : uint32_t
 // the stream between batches
 struct alignas(64) DeHead
 {
-    U128 state;                      // engine state in front of the next batch's first draw
+    U128 state;                      // engine state in front of the next batch to be resolved
     unsigned long long extra_total;  // draws thrown away so far
     uint32_t error;                  // kDeErr* bits, sticky
-    uint32_t pad[9];
+    uint32_t last_shift;             // draws thrown away inside the batch resolved last
+    // Where a batch is scanned from before the batch in front of it has been resolved: [b & 1] = the state in front of
+    // batch b had batch b - 1 thrown no draws away; its true first draw lies last_shift (of b - 1) draws further on.
+    U128 provisional[2];
 };
 static_assert(sizeof(DeHead) == 64, "one line");
 
@@ -124,8 +129,11 @@ struct DePlanArgs
 {
     DeHead* head;
     DeBatch* batch;               // the record the resolve writes
-    DeBad* bad;                   // [kDeSegments][bad_capacity]
+    DeBad* bad;                   // [kDeSegments][bad_capacity]: the lists the scan fills
     uint32_t* counts;             // [kDeSegments] at stride kDeCountStride
+    const DeBad* resolve_bad;     // the lists the resolve reads (the other of two sets: a scan runs beside it)
+    uint32_t* resolve_counts;
+    int scan_parity;              // the scan's batch & 1 (which provisional state it starts from)
     const Affine128* scan_hi;     // [ceil(scan lanes / 256)]  scan_run*256*j draws
     const Affine128* scan_lo;     // [256]                     scan_run*j draws
     const Affine128* jump_hi;     // [ceil(updates / 256)]     (D+3)*256*j draws
@@ -137,6 +145,7 @@ struct DePlanArgs
     int n, dims;
     int updates;                  // n * half-steps of this batch
     int positions;                // stream positions an update of the batch can start at: (D+3)(updates - 1) + kDeShiftMax + 1
+    int scan_positions;           // positions the scan looks at, from its provisional start: positions + kDeShiftMax + 1
     int scan_run;                 // consecutive positions one scanning lane steps through (the scan tables are built for it)
     int seg_len;                  // positions per list
     int bad_capacity;             // entries of one list

@@ -18,8 +18,8 @@ __device__ __forceinline__ void de_scan_lane(const DePlanArgs& a, int t)
     const uint64_t threshold = a.threshold;
     // (the loads first: the bounds come from the kernarg segment, which is cold)
     const Affine128 f_lo = a.scan_lo[t & 255], f_hi = a.scan_hi[t >> 8];
-    const U128 head_state = a.head->state;
-    const int positions = a.positions, run = a.scan_run;
+    const U128 head_state = a.head->provisional[a.scan_parity];
+    const int positions = a.scan_positions, run = a.scan_run;
     if ((long long)t * run >= positions) return;
     // the state behind run * t draws, then position after position
     U128 s = apply(f_lo, apply(f_hi, head_state));
@@ -118,12 +118,13 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
     static_assert(kDeSegments == 64, "one list per lane of the first wavefront");
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const DeHead head = *a.head;
+    const uint32_t behind = head.last_shift;
     uint32_t err = 0;
 
     if (wave == 0)
     {
         // the lists end to end: an inclusive scan of their lengths over the wavefront
-        const uint32_t listed = a.counts[(size_t)lane * kDeCountStride];
+        const uint32_t listed = a.resolve_counts[(size_t)lane * kDeCountStride];
         uint32_t sum = listed < (uint32_t)a.bad_capacity ? listed : (uint32_t)a.bad_capacity;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1)
@@ -133,7 +134,7 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
         }
         sh_off[lane + 1] = sum;
         if (lane == 0) sh_off[0] = 0;
-        a.counts[(size_t)lane * kDeCountStride] = 0;  // for the next batch's scan
+        a.resolve_counts[(size_t)lane * kDeCountStride] = 0;  // for the scan that fills these lists next
     }
     for (uint32_t r = (uint32_t)tid; r < per; r += (uint32_t)threads) sh_fill[r] = 0;
     __syncthreads();
@@ -153,7 +154,10 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
             else
                 hi = mid - 1;
         }
-        return a.bad[(size_t)lo * a.bad_capacity + ((uint32_t)idx - sh_off[lo])];
+        // the lists were made from the batch's provisional start: the true one lies `behind` draws further on
+        DeBad b = a.resolve_bad[(size_t)lo * a.bad_capacity + ((uint32_t)idx - sh_off[lo])];
+        b.p = (b.p >= behind && b.p - behind < (uint32_t)a.positions) ? b.p - behind : ~0u;  // (~0: not a position of this batch)
+        return b;
     };
     // Eight positions per lane at a time (their loads leave together), kept in registers between the two passes of the
     // counting sort when that is all there is (the usual case).
@@ -164,8 +168,12 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
         if (tid + u * threads < total) held[u] = entry(tid + u * threads);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
-        if (tid + u * threads < total) atomicAdd(&sh_fill[held[u].p % per], 1u);
-    for (int idx = tid + 8 * threads; idx < total; idx += threads) atomicAdd(&sh_fill[entry(idx).p % per], 1u);
+        if (tid + u * threads < total && held[u].p != ~0u) atomicAdd(&sh_fill[held[u].p % per], 1u);
+    for (int idx = tid + 8 * threads; idx < total; idx += threads)
+    {
+        const DeBad b = entry(idx);
+        if (b.p != ~0u) atomicAdd(&sh_fill[b.p % per], 1u);
+    }
     __syncthreads();
     if (wave == 0)
     {
@@ -192,6 +200,7 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
     }
     __syncthreads();
     auto place = [&](const DeBad& b) {
+        if (b.p == ~0u) return;
         const uint32_t q = b.p / per, res = b.p - q * per;
         sh_key[sh_start[res] + atomicAdd(&sh_fill[res], 1u)] = (q << 8) | (b.e & 0xFFu);
     };
@@ -262,9 +271,12 @@ __device__ __forceinline__ void de_resolve_block(const DePlanArgs& a, uint32_t* 
         out->base = head.state;
         out->extra_base = head.extra_total;
         out->events = events;
-        // hand the stream on
-        a.head->state = apply(a.jump_small[c], apply(a.batch_jump, head.state));
+        // hand the stream on: where the next batch begins, and where the one behind it is scanned from
+        const U128 next = apply(a.jump_small[c], apply(a.batch_jump, head.state));
+        a.head->state = next;
         a.head->extra_total = head.extra_total + (unsigned long long)c;
+        a.head->last_shift = c;
+        a.head->provisional[a.scan_parity ^ 1] = apply(a.batch_jump, next);  // (the batch behind the one scanned beside this resolve)
         if (err) atomicOr(&a.head->error, err);
     }
 }
@@ -341,24 +353,28 @@ __device__ __forceinline__ void de_records_block(const DePlanArgs& a, const DeBa
 }
 
 // ---- the launches ------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kDePlanThreads) de_scan_kernel(const DePlanArgs a)
-{
-    de_scan_lane(a, (int)blockIdx.x * kDePlanThreads + (int)threadIdx.x);
-}
-
-// workgroup 0 resolves batch a.batch (if resolve != 0); the others make the records of batch rec_batch into recs
-// (record_blocks of them; the two are independent: the records belong to the batch BEFORE the one being resolved)
+// In front of batch b (all three parts optional, for priming): workgroup 0 resolves batch b + 1 into a.batch; the next
+// record_blocks workgroups make the records of batch b from rec_batch; the rest scan batch b + 2.
 template <class T>
-__global__ void __launch_bounds__(kDePlanThreads) de_resolve_records_kernel(const DePlanArgs a, int resolve, int capacity, const DeBatch* rec_batch, DeRec<T>* recs)
+__global__ void __launch_bounds__(kDePlanThreads) de_boundary_kernel(const DePlanArgs a, int resolve, int capacity, int record_blocks, const DeBatch* rec_batch, DeRec<T>* recs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if (resolve != 0 && blockIdx.x == 0)
+    int block = (int)blockIdx.x;
+    if (resolve != 0)
     {
-        de_resolve_block(a, reinterpret_cast<uint32_t*>(smem), capacity, kDePlanThreads);
+        if (block == 0)
+        {
+            de_resolve_block(a, reinterpret_cast<uint32_t*>(smem), capacity, kDePlanThreads);
+            return;
+        }
+        --block;
+    }
+    if (block < record_blocks)
+    {
+        de_records_block<T>(a, rec_batch, recs, reinterpret_cast<DePlan*>(smem), block * kDePlanThreads, kDePlanThreads);
         return;
     }
-    const int rb = (int)blockIdx.x - (resolve != 0 ? 1 : 0);
-    de_records_block<T>(a, rec_batch, recs, reinterpret_cast<DePlan*>(smem), rb * kDePlanThreads, kDePlanThreads);
+    de_scan_lane(a, (block - record_blocks) * kDePlanThreads + (int)threadIdx.x);
 }
 
 // ---- behind a replay of `steps` ensemble steps: accepted proposals per step, then the run record moves on ---------------
