@@ -169,6 +169,25 @@ def test_device_differential_evolution_planning_batches_of_any_length(monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(graph_steps=3), dict(graph_steps=-1), dict(hip_stream=0)])
+def test_device_differential_evolution_short_replays_and_plain_launches(kw):
+    # graphs of three ensemble steps (every phase of a planning batch begins one), plain launches, and the legacy default
+    # stream (on which HIP cannot capture: plain launches too)
+    W, D, steps = 300, 5, 170
+    pos = po.init_positions(po.F64, W, D, salt=1)
+    orc = po.Oracle(W, D, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], seed=3, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
+    lp = orc.logp(pos)
+    orc.set_state(pos, lp)
+    want_chain, want_acc = orc.run(steps, 1)
+    s = capi.HipSampler(W, D, capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05], seed=3, mover=capi.MOVER_DIFFERENTIAL_EVOLUTION, **kw)
+    s.set_state(pos, lp)
+    chain, acc = s.run(steps, 1)
+    np.testing.assert_array_equal(chain, want_chain)
+    np.testing.assert_array_equal(acc, want_acc)
+    assert s.counters()["redraws"] == orc.redraws
+
+
+@pytest.mark.gpu
 def test_device_differential_evolution_dense_c2_shape_statistics():
     # BASELINE's C2 target under the other mover: same stationary distribution (variance 1 per parameter for the AR(1) covariance)
     from tests.golden.make_golden import ar1_precision
