@@ -74,6 +74,17 @@ __device__ __forceinline__ void full_step_draw_wave(const HalfStepArgs<T>& a, co
                          which == 0 ? run_ptr : nullptr, which == 0 ? run_behind_ctl : -1, ctl_chain);
 }
 
+// the one extra wavefront of a launch whose draw records were made ahead of it: the stored steps' forwarding only
+template <class T>
+__device__ __forceinline__ void full_step_trickle_wave(const StepCtl* ctl_ptr, int run_behind_ctl, int ctl_chain, int lane)
+{
+    StepCtl ctl;
+    RunInfo run;
+    const unsigned ctl_off = (unsigned)ctl_chain * (unsigned)kCtlChainStride;
+    load_records_and_warm_args<T>(ctl_ptr, ctl_off, ctl_ptr, ctl_off + (unsigned)kRunBehindCtlBytes - (unsigned)run_behind_ctl * (unsigned)sizeof(StepCtl), ctl, run);
+    trickle_stored_step(run, ctl, lane);
+}
+
 // Both full-step kernels update walkers [sh_begin, sh_begin + sh_count) of EACH colour (the whole halves, or the slice
 // of one rank of a split ensemble: a black walker's group repeats the update of its red partner wherever that one
 // lives, so the ranks exchange rows once per ensemble step instead of once per half-step).  The bounds travel in the
@@ -391,6 +402,13 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     const int lane = threadIdx.x & 63;
     if ((threadIdx.x >> 6) >= kWavesPerBlock)
     {
+        if ((hot_bits >> 20) & 1u)
+        {
+            // HalfStepArgs::draw_wave == 2: this step's records were made ahead of the launches (fill_draws_batch_kernel);
+            // the one extra wavefront forwards this launch's slice of the last stored step and that is all
+            if ((int)(threadIdx.x >> 6) == kWavesPerBlock) full_step_trickle_wave<T>(hot_ctl_in, h_flip ? 1 : 0, chain, lane);
+            return;
+        }
         // (the run record is read at an offset from the control record's address, where it is needed)
         full_step_draw_wave<T>(a, jump_tables_behind(draws_chain0, h_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in, nullptr, false, dn_red, h_n, sh_begin,
                                sh_count, kWavesPerBlock * NW, (int)(threadIdx.x >> 6) - kWavesPerBlock, lane, h_flip ? 1 : 0, chain);

@@ -72,15 +72,19 @@ void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
     const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
     const int chains = a.chains > 1 ? a.chains : 1;
-    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, 0, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity) |
+    // (the colour bit, meaningless for a full step, says that the draw records were made ahead: HalfStepArgs::draw_wave == 2;
+    //  such a launch has one extra wavefront per workgroup, the forwarder of stored steps, instead of the draw wavefronts)
+    const int prefilled = a.draw_wave == 2 ? 1 : 0;
+    const int extra_waves = prefilled ? 1 : kFullDrawWaves;
+    const uint32_t bits = full_step_bits(HotBits::pack(a.dims, 2, prefilled, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, 1, a.task_jump != nullptr), a.pos_parity) |
                           ((uint32_t)(chains - 1) << 28);
     // (logp_alt == logp + W, n_accept == logp + 2 W and the run record kRunBehindCtlBytes behind the control records: the
     //  kernel derives them and takes the padded matrix and the shard bounds as preloaded arguments instead)
     if (chains > 1 || a.chains < 0)  // (a.chains < 0: experiments -- the several-chains instantiation for one ensemble)
-        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, true>), dim3(grid, chains), dim3(64 * (kWavesPerBlock + extra_waves)), lds, st, a.draws,
                            a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
     else
-        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * (kWavesPerBlock + kFullDrawWaves)), lds, st, a.draws,
+        hipLaunchKernelGGL((stretch_full_step_mfma_kernel<T, Calc, EPL, LPW, false>), dim3(grid), dim3(64 * (kWavesPerBlock + extra_waves)), lds, st, a.draws,
                            a.pos, a.pos_alt, a.logp, a.calc_params_padded, a.shard_begin, a.shard_count, a.n, bits, a.ctl_in, a);
 }
 

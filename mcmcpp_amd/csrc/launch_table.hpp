@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430014u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430015u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -52,6 +52,9 @@ struct LaunchTable
 // red_base != nullptr: black records, with partner2 (see DrawRec)
 void launch_fill_draws(const HalfStepArgs<double>& a, U128 base, const U128* red_base, hipStream_t stream);
 void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_base, hipStream_t stream);
+// the records of `steps` ensemble steps from the one whose control record is `ctl` on (fill_draws_batch_kernel)
+void launch_fill_draws_batch(const HalfStepArgs<double>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<double>* out, int steps, hipStream_t stream);
+void launch_fill_draws_batch(const HalfStepArgs<float>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<float>* out, int steps, hipStream_t stream);
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains = 1);
 

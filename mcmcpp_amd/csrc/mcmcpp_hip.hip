@@ -90,6 +90,7 @@ struct Knobs
     long debug_timing;            // MCMCPP_HIP_DEBUG_TIMING             1: run() prints its host-side phases to stderr
     long trickle;                 // MCMCPP_HIP_TRICKLE                  1: stored steps forwarded to pinned memory by the launches (1)
     long no_draw_wave;            // MCMCPP_HIP_NO_DRAW_WAVE             1: no extra draw wavefronts (0)
+    long batch_draws;             // MCMCPP_HIP_BATCH_DRAWS              ensemble steps whose draw records one launch makes ahead of the matrix-core full-step launches; 0: the launches make them themselves (128)
     long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
@@ -111,6 +112,7 @@ struct Knobs
         k.debug_timing = env_long("MCMCPP_HIP_DEBUG_TIMING", 0);
         k.trickle = env_long("MCMCPP_HIP_TRICKLE", 1);
         k.no_draw_wave = env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0);
+        k.batch_draws = env_long("MCMCPP_HIP_BATCH_DRAWS", 128);
         k.copy_stream = env_long("MCMCPP_HIP_COPY_STREAM", 0);
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
@@ -189,6 +191,16 @@ void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_
 {
     const unsigned grid = (unsigned)((3 * (long)a.shard_count + 255) / 256);
     hipLaunchKernelGGL(fill_draws_kernel<float>, dim3(grid), dim3(256), 0, stream, a, base, red_base ? *red_base : base, red_base ? 1 : 0);
+}
+void launch_fill_draws_batch(const HalfStepArgs<double>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<double>* out, int steps, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((a.shard_count + 63) / 64);
+    hipLaunchKernelGGL(fill_draws_batch_kernel<double>, dim3(grid, (unsigned)(2 * steps)), dim3(192), 0, stream, a, ctl, step_jump, out);
+}
+void launch_fill_draws_batch(const HalfStepArgs<float>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<float>* out, int steps, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((a.shard_count + 63) / 64);
+    hipLaunchKernelGGL(fill_draws_batch_kernel<float>, dim3(grid, (unsigned)(2 * steps)), dim3(192), 0, stream, a, ctl, step_jump, out);
 }
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
                             const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains)
@@ -469,6 +481,19 @@ public:
             HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
         }
         half_jump = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n);
+        // Draw records made ahead of the step launches, a batch of steps per launch (fill_draws_batch_kernel): for the
+        // matrix-core full-step kernel of one whole ensemble on one device.  step_jump[j]: the draws of j ensemble steps.
+        batch_draws = 0;
+        if (full_fn && full_fn == table->full_step_mc[lpw_log][epl_shift] && K == 1 && c.comm_world < 1 && whole && knobs.batch_draws >= 1 && knobs.no_draw_wave == 0)
+        {
+            batch_draws = (int)(knobs.batch_draws > 256 ? 256 : knobs.batch_draws);
+            HIP_TRY(hipMalloc(&d_draws_batch, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));
+            HIP_TRY(hipMemset(d_draws_batch, 0, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));  // (partner indices a kernel may follow)
+            std::vector<Affine128> sj((size_t)batch_draws);
+            for (int j = 0; j < batch_draws; ++j) sj[(size_t)j] = pcg_jump(inc, (unsigned __int128)6 * (unsigned)n * (unsigned)j);
+            HIP_TRY(hipMalloc(&d_step_jump, sizeof(Affine128) * sj.size()));
+            HIP_TRY(hipMemcpy(d_step_jump, sj.data(), sizeof(Affine128) * sj.size(), hipMemcpyHostToDevice));
+        }
         if (have_task_table)
         {
             std::vector<Affine128> tj((size_t)3 * n);
@@ -740,8 +765,9 @@ public:
             last_launches = full_fn ? total : 2 * total;  // (a launch steps all chains)
             half_steps += 2 * (uint64_t)total;
             steps_since_reset += (uint64_t)total;
-            // the last launch left the records of the next ensemble step behind (full-step launches: with partner2)
-            records_valid = true;
+            // the last launch left the records of the next ensemble step behind (full-step launches: with partner2) --
+            // unless the records were made ahead in batches, which leaves the two-buffer records alone
+            records_valid = batch_draws == 0;
             records_step = half_steps >> 1;
             records_partner2 = full_fn != nullptr;
             if (accepted_per_step)
@@ -1433,7 +1459,8 @@ private:
     }
 
     // pos_parity: which position buffer a full-step launch reads (ensemble steps enqueued in this run() & 1)
-    void enqueue_step(int parity, int pos_parity)
+    // batch_slot >= 0: the step's draw records are record set batch_slot of d_draws_batch, made ahead (fill_batch)
+    void enqueue_step(int parity, int pos_parity, int batch_slot = -1)
     {
         if (full_fn)
         {
@@ -1445,13 +1472,44 @@ private:
             a.partial_waves = partial_waves;
             // the next draws by four extra wavefronts (two per colour) when that is one round of 64 draws each
             a.draw_wave = (3 * (kFullDrawWaves == 4 ? (full_wpb + 1) / 2 : full_wpb) <= 64 && knobs.no_draw_wave == 0) ? 1 : 0;
+            if (batch_slot >= 0)
+            {
+                a.draw_wave = 2;
+                a.draw_parity = 0;
+                a.draws = d_draws_batch + (size_t)batch_slot * 2 * (size_t)n;
+            }
             full_fn(a, full_grid_blocks_for(a.shard_count), stream);
+            a.draws = d_draws;
             return;
         }
         args_red.draw_parity = parity;
         args_blk.draw_parity = parity;
         half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
         half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
+    }
+
+    // the draw records of `count` ensemble steps from the one that reads position buffer pos_parity on (its control
+    // record is what the launch before it left behind, or write_ctl)
+    void fill_batch(int pos_parity, int count)
+    {
+        HalfStepArgs<T> a = args_red;
+        a.draws = d_draws;
+        launch_fill_draws_batch(a, d_ctl + pos_parity, d_step_jump, d_draws_batch, count, stream);
+    }
+
+    // `steps` ensemble steps from record-buffer parity start_parity / position-buffer parity pos_parity on
+    void enqueue_step_sequence(int steps, int start_parity, int pos_parity)
+    {
+        for (int s = 0; s < steps; ++s)
+        {
+            if (batch_draws > 0)
+            {
+                if (s % batch_draws == 0) fill_batch((pos_parity + s) & 1, steps - s < batch_draws ? steps - s : batch_draws);
+                enqueue_step(0, (pos_parity + s) & 1, s % batch_draws);
+            }
+            else
+                enqueue_step((start_parity + s) & 1, (pos_parity + s) & 1);
+        }
     }
 
     // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
@@ -1465,7 +1523,7 @@ private:
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            for (int s = 0; s < steps; ++s) enqueue_step((start_parity + s) & 1, (pos_parity + s) & 1);
+            enqueue_step_sequence(steps, start_parity, pos_parity);
             launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream, K);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
@@ -1518,7 +1576,7 @@ private:
         {
             for (; left > 0; --left)
             {
-                enqueue_step((int)(enq_step & 1), (int)(run_step & 1));
+                enqueue_step_sequence(1, (int)(enq_step & 1), (int)(run_step & 1));
                 launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
                 enq_step += 1;
                 run_step += 1;
@@ -1599,6 +1657,8 @@ private:
             if (ex) hipGraphExecDestroy(ex);
         if (arena) hipFree(arena);  // positions, log-posteriors, counters, records, tables, parameters, partial counts
         if (d_acc) hipFree(d_acc);
+        if (d_draws_batch) hipFree(d_draws_batch);
+        if (d_step_jump) hipFree(d_step_jump);
         for (int k = 0; k < 2; ++k)
         {
             if (d_chain[k]) hipFree(d_chain[k]);
@@ -1663,6 +1723,9 @@ private:
     RunInfo* d_run = nullptr;
     Diag* d_diag = nullptr;
     DrawRec<T>* d_draws = nullptr;
+    DrawRec<T>* d_draws_batch = nullptr;  // [batch_draws][2][n]: records made ahead of the matrix-core full-step launches
+    Affine128* d_step_jump = nullptr;     // [batch_draws]
+    int batch_draws = 0;                  // 0: the step launches make their own next records
     static constexpr size_t kStampWords = 8 + 2 * 3 * 4096 + 8;
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     uint32_t* d_partials = nullptr;

@@ -995,6 +995,36 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
                     with_partner2 != 0, red_base);
 }
 
+// The records of whole ensemble steps, made AHEAD of the launches that use them (full-step launches with
+// HalfStepArgs::draw_wave == 2): blockIdx.y = 2 * j + colour for step j behind the one whose control record is `ctl`
+// (step_jump[j]: 6 n j draws).  The draws do not depend on the walkers; made 128 steps at a time by a launch of their
+// own they cost a step launch 0.1 us less than made by its four extra wavefronts (C2: 5.65 -> 5.56 us per ensemble
+// step, the fill launch's 4.5 us included -- DESIGN.md, experiment 3e).
+// Workgroups of three wavefronts: wavefront k makes draw k (partner | z and (D-1) ln z | ln U) of 64 walkers, so that a
+// wavefront runs ONE of the three kinds of arithmetic instead of all three in turn (draws 3 i + k in lane order, as the
+// half-step priming kernel above has them, diverge three ways).
+template <class T>
+__global__ void __launch_bounds__(192) fill_draws_batch_kernel(const HalfStepArgs<T> a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<T>* out)
+{
+    const int k = (int)threadIdx.x >> 6;
+    const int slot = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63);
+    if (slot >= a.shard_count) return;
+    const int j = (int)blockIdx.y >> 1, colour = (int)blockIdx.y & 1;
+    const int i = a.shard_begin + slot;
+    const bool direct = a.task_jump != nullptr;
+    Affine128 j_a, j_b;
+    if (direct)
+        j_a = a.task_jump[3 * i + k];
+    else
+    {
+        j_a = a.jump_hi[i >> 8];
+        j_b = a.jump_lo[i & 255];
+    }
+    const U128 red_base = apply(step_jump[j], ctl->state);
+    const U128 base = colour ? apply(a.half_jump, red_base) : red_base;
+    compute_draw<T>(a, base, j_a, j_b, direct, k, out + ((size_t)j * 2 + (size_t)colour) * (size_t)a.n + i, colour != 0, red_base);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Matrix-core variant for calculators whose log-posterior contains a dense D x D product (the correlated
 // Gaussian): a wavefront updates 16 walkers at once and evaluates  Y = X * P^T  ([16 walkers x 32] x [32 x 32])

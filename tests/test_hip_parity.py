@@ -184,6 +184,23 @@ def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D, step_path):
     _assert_same_state(orc, hip)
 
 
+@pytest.mark.parametrize("batch", ["0", "1", "7", "128"])
+def test_draw_records_made_ahead_in_batches_of_any_length(monkeypatch, batch):
+    """The matrix-core full-step launches of one whole ensemble read draw records made ahead by a launch of their own,
+    MCMCPP_HIP_BATCH_DRAWS ensemble steps at a time (0: their own extra wavefronts make them, as for chains and split
+    ensembles): the chain must not depend on it, across runs that end inside a batch, with and without stored steps."""
+    monkeypatch.setenv("MCMCPP_HIP_BATCH_DRAWS", batch)
+    orc, hip = _oracle_and_hip(2048 + 6, 32, po.CALC_DENSE_GAUSSIAN, po.F64, seed=5, steps=0)
+    oc, oa = orc.run(45, interval=3, mode=po.MODE_COUNTER, threads=4)
+    got = [hip.run(k, interval=3) for k in (1, 9, 5)]
+    hip.run(10, interval=3, save_chain=False)
+    got.append(hip.run(20, interval=3))
+    np.testing.assert_array_equal(np.concatenate([g[0] for g in got[:3]]), oc[:15])
+    np.testing.assert_array_equal(got[3][0], oc[25:])
+    np.testing.assert_array_equal(np.concatenate([g[1] for g in got[:3]]), oa[:45])
+    _assert_same_state(orc, hip)
+
+
 def test_checkpoint_and_resume_in_a_new_handle(step_path):
     """get_state + the number of steps done is a complete checkpoint: a fresh handle resumes the trajectory."""
     orc, hip = _oracle_and_hip(1024, 16, po.CALC_DENSE_GAUSSIAN, po.F64, seed=21, steps=0)
