@@ -46,6 +46,17 @@ public:
         if (epl_shift >= kMaxEplShift || !table->de_update[lpw_log][epl_shift])
             return fail(MCMCPP_HIP_E_UNSUPPORTED, "no differential-evolution kernel for D=%d with this calculator (LPW=%d EPL=%d)", D, lpw, epl);
         update_fn = table->de_update[lpw_log][epl_shift];
+        walkers_per_block = (64 / lpw) * kWavesPerBlock;
+        {
+            // the dense Gaussian's product on the matrix cores (de_update_mfma_kernel): fp64, even D, 8 walkers per wavefront
+            const char* v = std::getenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS");
+            const long mc_min = (v && *v) ? std::strtol(v, nullptr, 10) : 0;
+            if (table->de_update_mc[lpw_log][epl_shift] && c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN && D % 2 == 0 && mc_min >= 0 && n >= mc_min)
+            {
+                update_fn = table->de_update_mc[lpw_log][epl_shift];
+                walkers_per_block = 8 * kWavesPerBlock;
+            }
+        }
         calc_fn = table->calc[lpw_log][epl_shift];
         vec_ok = (D % base == 0) ? 1 : 0;
 
@@ -124,7 +135,7 @@ public:
         // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
         if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
         replay_steps_max = graph_steps >= 1 ? graph_steps : 16;  // (plain launches: enqueued in groups of this many steps)
-        const int per_block = (64 / lpw) * kWavesPerBlock;
+        const int per_block = walkers_per_block;
         update_blocks = (n + per_block - 1) / per_block;
         partial_waves = update_blocks * kWavesPerBlock;
         HIP_TRY(hipMalloc(&d_head, sizeof(DeHead)));
@@ -621,7 +632,7 @@ private:
     const LaunchTable<T>* table = nullptr;
     typename LaunchTable<T>::DeFn update_fn = nullptr;
     typename LaunchTable<T>::CalcFn calc_fn = nullptr;
-    int W = 0, D = 0, n = 0, lpw = 1, epl = 1, vec_ok = 0, device = -1;
+    int W = 0, D = 0, n = 0, lpw = 1, epl = 1, vec_ok = 0, device = -1, walkers_per_block = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false, have_state = false;
     T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_chain = nullptr;

@@ -292,4 +292,140 @@ de_update_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>
     }
 }
 
+// ---- the same update for the dense Gaussian on the matrix cores (fp64, 17..32 even dimensions) ----------------------------
+// As stretch_half_step_mfma_kernel: a wavefront's 4 P walkers are the rows of one 16-row tile -- walker (pass q, lane
+// group g) is row 4 q + g; lane (g, sub) holds elements 2 sub, 2 sub + 1 of its P walkers -- and Y = X * P^T runs on
+// v_mfma_f64_16x16x4_f64 (mc_eval: bit for bit the host calculator's fma chain).  Everything else is de_update_kernel.
+template <class T, class Calc, int EPL, int LPW, int P>
+__global__ void __launch_bounds__(64 * kWavesPerBlock)
+de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>* hot_recs, const Affine128* hot_jump_small, DeRunInfo* hot_run, int hot_n,
+                      uint32_t hot_bits, int hot_step, const DeArgs<T> a)
+{
+    static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
+    constexpr int NW = 4 * P;  // walkers per wavefront
+    constexpr int kThreads = 64 * kWavesPerBlock;
+    // LDS: [P^T zero-padded to 32 x 32 (workgroup)][proposal rows, NW x kMcXS per wavefront]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* sh_pt = reinterpret_cast<T*>(smem);
+    T* sh_x = sh_pt + 32 * 32 + (threadIdx.x >> 6) * (NW * kMcXS);
+    const int dims = (int)(hot_bits & 0xFFFu), n = hot_n;
+    const int lane = threadIdx.x & 63;
+    const int color = (int)((hot_bits >> 12) & 1u);
+    const int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
+    const int first = wave * NW;
+    const bool wave_active = first < n;
+    const int half_base = color ? n : 0, other_base = color ? 0 : n;
+    const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
+    // (the host only selects this kernel for even D: rows are whole 16-byte pieces, every access is branch-free)
+    typedef double2 V2;
+    const bool col_ok = i0 < dims;
+    const int i0c = col_ok ? i0 : 0;
+
+    // first round trip, from preloaded arguments only
+    DeRec<T> rec[P];
+    T own[P][2], lp_old[P];
+    uint32_t nacc_old[P];
+    bool active[P];
+    int w[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const int k = first + 4 * q + grp;
+        active[q] = wave_active && k < n;
+        const int kk = active[q] ? k : 0;
+        w[q] = half_base + kk;
+        rec[q] = hot_recs[kk];
+        const V2 v = *reinterpret_cast<const V2*>(hot_pos + (size_t)w[q] * dims + i0c);
+        own[q][0] = (active[q] && col_ok) ? v.x : (T)0;
+        own[q][1] = (active[q] && col_ok) ? v.y : (T)0;
+        lp_old[q] = hot_logp[w[q]];
+        nacc_old[q] = hot_n_accept[w[q]];
+    }
+    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 : dims];
+    void* const run_chain = assume_global(hot_run->chain);
+    const long long run_slot0 = hot_run->slot0;
+    const uint32_t run_interval = hot_run->interval, run_phase0 = hot_run->phase0;
+    typename Calc::Prefetch calc_pf;
+    Calc::block_prefetch(calc_pf, a.calc_params, dims, true, (int)threadIdx.x, kThreads);
+
+    // second round trip: the two partner rows of every pass
+    T w1[P][2], w2[P][2];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const V2 v1 = *reinterpret_cast<const V2*>(hot_pos + (size_t)(other_base + (active[q] ? (int)rec[q].ind1 : 0)) * dims + i0c);
+        const V2 v2 = *reinterpret_cast<const V2*>(hot_pos + (size_t)(other_base + (active[q] ? (int)rec[q].ind2 : 0)) * dims + i0c);
+        w1[q][0] = v1.x, w1[q][1] = v1.y, w2[q][0] = v2.x, w2[q][1] = v2.y;
+    }
+    // in its shadow: the matrix goes to LDS, the lanes draw their jitters
+    Calc::block_commit(calc_pf, sh_pt, a.calc_params, dims, true, (int)threadIdx.x, kThreads);
+    __syncthreads();
+    if (!wave_active) return;
+
+    const uint32_t since = run_phase0 + (uint32_t)hot_step;
+    const uint32_t whole = since / run_interval;
+    const bool saved_step = since - whole * run_interval + 1u == run_interval;
+    long long save_slot = (run_chain != nullptr && saved_step) ? run_slot0 + (long long)whole : -1;
+    asm volatile("" : "+v"(save_slot));  // (see de_update_kernel)
+
+    T prop[P][2];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        // the jitters of this lane's elements (draws i0, i0 + 1 behind the integer draws): MultiSampler.h:66
+        U128 su = apply(j_uni, rec[q].s);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+        {
+            su = pcg_step(su, a.inc);
+            const T u = canonical(pcg_output(su), T());
+            const T jit = a.jitter_low + (u * a.jitter_width);
+            const T d = w1[q][e] - w2[q][e];
+            const T gd = a.gamma * d;
+            const T moved = own[q][e] + gd;
+            const T p = moved + jit;
+            prop[q][e] = (active[q] && col_ok) ? p : (T)0;  // padded cells stay +0
+        }
+    }
+    McB matB;
+    mc_load_b(sh_pt, sub, grp, matB);
+    T lp_new[P];
+    mc_eval<P>(matB, sh_x, sub, grp, dims, prop, lp_new);
+
+    unsigned acc = 0;
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+    {
+        const T neg_exp = rec[q].neg_exp;
+        const T delta = lp_new[q] - lp_old[q];
+        const bool accept = active[q] && (delta > neg_exp);  // DifferentialEvolution.h:100
+        if (active[q] && sub == 0)
+        {
+            const T margin = dev_abs(neg_exp - delta);
+            const T scale = dev_abs(neg_exp) + dev_abs(lp_new[q]) + dev_abs(lp_old[q]);
+            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+        }
+        if (accept)
+        {
+            if (col_ok) *reinterpret_cast<V2*>(hot_pos + (size_t)w[q] * dims + i0) = make_double2(prop[q][0], prop[q][1]);
+            if (sub == 0)
+            {
+                hot_logp[w[q]] = lp_new[q];
+                hot_n_accept[w[q]] = nacc_old[q] + 1u;
+            }
+        }
+        if (save_slot >= 0 && active[q] && col_ok)
+        {
+            T* crow = reinterpret_cast<T*>(run_chain) + ((size_t)save_slot * (size_t)(2 * n) + (size_t)w[q]) * dims;
+            *reinterpret_cast<V2*>(crow + i0) = accept ? make_double2(prop[q][0], prop[q][1]) : make_double2(own[q][0], own[q][1]);
+        }
+        acc += (unsigned)__popcll(__ballot(accept && sub == 0));
+    }
+    if (lane == 0)
+    {
+        uint32_t* partials = reinterpret_cast<uint32_t*>(hot_run + 1);
+        partials[((size_t)hot_step * 2 + (size_t)color) * (size_t)a.partial_waves + (size_t)wave] = acc;
+    }
+}
+
 }  // namespace mcmcpp

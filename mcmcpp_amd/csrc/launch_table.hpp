@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430015u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430016u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -47,6 +47,8 @@ struct LaunchTable
     };
     typedef void (*DeFn)(const DeLaunch&, const DeArgs<T>&, unsigned grid, hipStream_t);
     DeFn de_update[kLpwLevels][kMaxEplShift];
+    // matrix-core variant (nullptr where the calculator has none): 8 walkers per wavefront, even D only
+    DeFn de_update_mc[kLpwLevels][kMaxEplShift];
 };
 
 // red_base != nullptr: black records, with partner2 (see DrawRec)
