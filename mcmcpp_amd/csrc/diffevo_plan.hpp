@@ -11,6 +11,15 @@ __device__ __forceinline__ uint32_t de_bounded(uint64_t v, int n, bool pow2) { r
 
 // ---- scan: every stream position of the batch, drawn once; the bad ones listed ------------------------------------------
 // t: the scanning lane (of the whole batch)
+// the low 32 bits of the XSL-RR output of state s (pcg_output), through one funnel shift instead of a 64-bit rotate
+__device__ __forceinline__ uint32_t de_output_low(U128 s)
+{
+    const uint64_t x = s.hi ^ s.lo;
+    const uint32_t xl = (uint32_t)x, xh = (uint32_t)(x >> 32);
+    const uint32_t rot = (uint32_t)(s.hi >> 58);
+    return (rot & 32u) ? __builtin_amdgcn_alignbit(xl, xh, rot & 31u) : __builtin_amdgcn_alignbit(xh, xl, rot & 31u);
+}
+
 __device__ __forceinline__ void de_scan_lane(const DePlanArgs& a, int t)
 {
     const int n = a.n;
@@ -21,9 +30,67 @@ __device__ __forceinline__ void de_scan_lane(const DePlanArgs& a, int t)
     const U128 head_state = a.head->provisional[a.scan_parity];
     const int positions = a.scan_positions, run = a.scan_run;
     if ((long long)t * run >= positions) return;
+    // a bad position: DifferentialEvolution.h:83-87 from this position on (rare: one position in n), listed with its E
+    auto list_bad = [&](int p, U128 w, uint64_t v) {
+        int used = 1;
+        while (v < threshold && used < kDeWindow)
+        {
+            w = pcg_step(w, a.inc);
+            v = pcg_output(w);
+            ++used;
+        }
+        const uint32_t ind1 = de_bounded(v, n, pow2);
+        bool overrun = v < threshold;
+        uint32_t ind2 = ind1;
+        while (!overrun && ind2 == ind1)
+        {
+            do
+            {
+                if (used >= kDeWindow)
+                {
+                    overrun = true;
+                    break;
+                }
+                w = pcg_step(w, a.inc);
+                v = pcg_output(w);
+                ++used;
+            } while (v < threshold);
+            if (!overrun) ind2 = de_bounded(v, n, pow2);
+        }
+        const int seg = p / a.seg_len;
+        const uint32_t slot = atomicAdd(a.counts + (size_t)seg * kDeCountStride, 1u);
+        if (slot < (uint32_t)a.bad_capacity)
+        {
+            DeBad b;
+            b.p = (uint32_t)p;
+            b.e = overrun ? (uint32_t)kDeOverrun : (uint32_t)(used - 2);
+            a.bad[(size_t)seg * a.bad_capacity + slot] = b;
+        }
+        else
+            atomicOr(&a.head->error, kDeErrCand);
+    };
     // the state behind run * t draws, then position after position
     U128 s = apply(f_lo, apply(f_hi, head_state));
     s = pcg_step(s, a.inc);
+    if (pow2)
+    {
+        // A power-of-two half (the threshold is 0: no draw is thrown away for its own sake): a position is bad when the
+        // two draws there name the same walker, i.e. agree in the low bits of their outputs -- which one funnel shift
+        // per draw gives (n <= 2^30), no 64-bit rotate, no 64-bit compares.
+        const uint32_t mask = (uint32_t)(n - 1);
+        uint32_t ind = de_output_low(s) & mask;
+#pragma unroll 1
+        for (int i = 0; i < run; ++i)
+        {
+            const int p = t * run + i;
+            const U128 s_next = pcg_step(s, a.inc);
+            const uint32_t ind_next = de_output_low(s_next) & mask;
+            if (p < positions && ind == ind_next) list_bad(p, s, pcg_output(s));
+            s = s_next;
+            ind = ind_next;
+        }
+        return;
+    }
     uint64_t raw = pcg_output(s);
     uint32_t ind = de_bounded(raw, n, pow2);
 #pragma unroll 1
@@ -34,49 +101,7 @@ __device__ __forceinline__ void de_scan_lane(const DePlanArgs& a, int t)
         const uint64_t nxt = pcg_output(s_next);
         const uint32_t ind_next = de_bounded(nxt, n, pow2);
         // bad: a draw below the threshold, or both draws naming the same walker -- an update starting here throws draws away
-        const bool is_bad = p < positions && (raw < threshold || nxt < threshold || ind == ind_next);
-        if (is_bad)
-        {
-            // DifferentialEvolution.h:83-87 from this position on (rare: one position in n)
-            U128 w = s;
-            uint64_t v = raw;
-            int used = 1;
-            while (v < threshold && used < kDeWindow)
-            {
-                w = pcg_step(w, a.inc);
-                v = pcg_output(w);
-                ++used;
-            }
-            const uint32_t ind1 = de_bounded(v, n, pow2);
-            bool overrun = v < threshold;
-            uint32_t ind2 = ind1;
-            while (!overrun && ind2 == ind1)
-            {
-                do
-                {
-                    if (used >= kDeWindow)
-                    {
-                        overrun = true;
-                        break;
-                    }
-                    w = pcg_step(w, a.inc);
-                    v = pcg_output(w);
-                    ++used;
-                } while (v < threshold);
-                if (!overrun) ind2 = de_bounded(v, n, pow2);
-            }
-            const int seg = p / a.seg_len;
-            const uint32_t slot = atomicAdd(a.counts + (size_t)seg * kDeCountStride, 1u);
-            if (slot < (uint32_t)a.bad_capacity)
-            {
-                DeBad b;
-                b.p = (uint32_t)p;
-                b.e = overrun ? (uint32_t)kDeOverrun : (uint32_t)(used - 2);
-                a.bad[(size_t)seg * a.bad_capacity + slot] = b;
-            }
-            else
-                atomicOr(&a.head->error, kDeErrCand);
-        }
+        if (p < positions && (raw < threshold || nxt < threshold || ind == ind_next)) list_bad(p, s, raw);
         s = s_next;
         raw = nxt;
         ind = ind_next;
