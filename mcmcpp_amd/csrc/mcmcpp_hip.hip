@@ -90,7 +90,7 @@ struct Knobs
     long debug_timing;            // MCMCPP_HIP_DEBUG_TIMING             1: run() prints its host-side phases to stderr
     long trickle;                 // MCMCPP_HIP_TRICKLE                  1: stored steps forwarded to pinned memory by the launches (1)
     long no_draw_wave;            // MCMCPP_HIP_NO_DRAW_WAVE             1: no extra draw wavefronts (0)
-    long batch_draws;             // MCMCPP_HIP_BATCH_DRAWS              ensemble steps whose draw records one launch makes ahead of the matrix-core full-step launches; 0: the launches make them themselves (128)
+    long batch_draws;             // MCMCPP_HIP_BATCH_DRAWS              ensemble steps whose draw records one launch makes ahead of the matrix-core full-step launches; 0: the launches make them themselves; -1: as many as a graph replays (-1)
     long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
@@ -112,7 +112,7 @@ struct Knobs
         k.debug_timing = env_long("MCMCPP_HIP_DEBUG_TIMING", 0);
         k.trickle = env_long("MCMCPP_HIP_TRICKLE", 1);
         k.no_draw_wave = env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0);
-        k.batch_draws = env_long("MCMCPP_HIP_BATCH_DRAWS", 128);
+        k.batch_draws = env_long("MCMCPP_HIP_BATCH_DRAWS", -1);
         k.copy_stream = env_long("MCMCPP_HIP_COPY_STREAM", 0);
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
@@ -481,19 +481,6 @@ public:
             HIP_TRY(hipMemcpy(d_jump_hi, hi.data(), sizeof(Affine128) * hi.size(), hipMemcpyHostToDevice));
         }
         half_jump = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n);
-        // Draw records made ahead of the step launches, a batch of steps per launch (fill_draws_batch_kernel): for the
-        // matrix-core full-step kernel of one whole ensemble on one device.  step_jump[j]: the draws of j ensemble steps.
-        batch_draws = 0;
-        if (full_fn && full_fn == table->full_step_mc[lpw_log][epl_shift] && K == 1 && c.comm_world < 1 && whole && knobs.batch_draws >= 1 && knobs.no_draw_wave == 0)
-        {
-            batch_draws = (int)(knobs.batch_draws > 256 ? 256 : knobs.batch_draws);
-            HIP_TRY(hipMalloc(&d_draws_batch, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));
-            HIP_TRY(hipMemset(d_draws_batch, 0, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));  // (partner indices a kernel may follow)
-            std::vector<Affine128> sj((size_t)batch_draws);
-            for (int j = 0; j < batch_draws; ++j) sj[(size_t)j] = pcg_jump(inc, (unsigned __int128)6 * (unsigned)n * (unsigned)j);
-            HIP_TRY(hipMalloc(&d_step_jump, sizeof(Affine128) * sj.size()));
-            HIP_TRY(hipMemcpy(d_step_jump, sj.data(), sizeof(Affine128) * sj.size(), hipMemcpyHostToDevice));
-        }
         if (have_task_table)
         {
             std::vector<Affine128> tj((size_t)3 * n);
@@ -507,6 +494,21 @@ public:
         // HIP cannot capture on the legacy default stream (hipErrorStreamCaptureUnsupported): a caller that hands over
         // NULL / hipStreamLegacy gets plain launches instead of graph replays
         if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
+        // Draw records made ahead of the step launches, a batch of steps per launch (fill_draws_batch_kernel): for the
+        // matrix-core full-step kernel of one whole ensemble on one device.  step_jump[j]: the draws of j ensemble steps.
+        batch_draws = 0;
+        if (full_fn && full_fn == table->full_step_mc[lpw_log][epl_shift] && K == 1 && c.comm_world < 1 && whole && knobs.batch_draws != 0 && knobs.no_draw_wave == 0)
+        {
+            // (by default as many steps as a graph replays: one fill launch per replay)
+            const long want = knobs.batch_draws > 0 ? knobs.batch_draws : (graph_steps >= 1 ? (long)graph_steps : 128L);
+            batch_draws = (int)(want > 512 ? 512 : want);
+            HIP_TRY(hipMalloc(&d_draws_batch, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));
+            HIP_TRY(hipMemset(d_draws_batch, 0, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));  // (partner indices a kernel may follow)
+            std::vector<Affine128> sj((size_t)batch_draws);
+            for (int j = 0; j < batch_draws; ++j) sj[(size_t)j] = pcg_jump(inc, (unsigned __int128)6 * (unsigned)n * (unsigned)j);
+            HIP_TRY(hipMalloc(&d_step_jump, sizeof(Affine128) * sj.size()));
+            HIP_TRY(hipMemcpy(d_step_jump, sj.data(), sizeof(Affine128) * sj.size(), hipMemcpyHostToDevice));
+        }
         partial_slots = graph_steps >= 1 ? graph_steps : 1;
         partial_waves = (int)(full_fn ? full_grid_blocks() : grid_blocks()) * kWavesPerBlock;
         if ((int)grid_blocks() * kWavesPerBlock > partial_waves) partial_waves = (int)grid_blocks() * kWavesPerBlock;

@@ -1,8 +1,7 @@
 #!/bin/bash
-# draw records made ahead in batches (MCMCPP_HIP_BATCH_DRAWS) against the launches making their own: parity, then the C2 launch time
+# draw records made ahead in batches (MCMCPP_HIP_BATCH_DRAWS) against the launches making their own: the C2 launch time
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/ab_libs2.log
 : > $out
-timeout -k 10 600 python -m pytest tests/test_hip_parity.py tests/test_async_pinned.py tests/test_facade.py -x -q -m gpu 2>&1 | tail -3 >> $out
-for b in 32 0 8 16 64 128 32; do echo "== MCMCPP_HIP_BATCH_DRAWS=$b" >> $out; MCMCPP_HIP_BATCH_DRAWS=$b timeout -k 5 90 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3e walker-steps/s, %.2f ms per step, launch %.3f us, acceptance %.4f' % (d['value'], d['ms_per_step'], d['roofline'].get('avg_launch_us', 0), d['acceptance_rate']))" >> $out 2>&1; done
+for b in 128 0 32 256 300 150 128; do echo "== MCMCPP_HIP_BATCH_DRAWS=$b" >> $out; MCMCPP_HIP_BATCH_DRAWS=$b timeout -k 5 90 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('%.3e walker-steps/s, %.2f ms per step, launch %.3f us, acceptance %.4f' % (d['value'], d['ms_per_step'], d['roofline'].get('avg_launch_us', 0), d['acceptance_rate']))" >> $out 2>&1; done
 cat $out
