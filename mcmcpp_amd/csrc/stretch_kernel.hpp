@@ -999,7 +999,7 @@ __global__ void __launch_bounds__(256) fill_draws_kernel(const HalfStepArgs<T> a
 // HalfStepArgs::draw_wave == 2): blockIdx.y = 2 * j + colour for step j behind the one whose control record is `ctl`
 // (step_jump[j]: 6 n j draws).  The draws do not depend on the walkers; made a graph replay's worth at a time by a launch
 // of their own they cost a step launch 0.1 us less than made by its four extra wavefronts (C2: 5.65 -> 5.52 us per
-// ensemble step, the fill launch's 4.5 us per 300 steps included -- DESIGN.md, experiment 3e).
+// ensemble step, the fill launch's 0.18 us per step included -- DESIGN.md, experiment 3e).
 // Workgroups of three wavefronts: wavefront k makes draw k (partner | z and (D-1) ln z | ln U) of 64 walkers, so that a
 // wavefront runs ONE of the three kinds of arithmetic instead of all three in turn (draws 3 i + k in lane order, as the
 // half-step priming kernel above has them, diverge three ways).
