@@ -54,7 +54,6 @@ constexpr int kDeMaxBad = 8192;     // bad positions of a batch the resolver hol
 constexpr int kDeMaxEvents = 1024;  // events of a batch
 constexpr int kDeScanRun = 8;       // consecutive stream positions one scanning lane steps through (default)
 constexpr int kDePlanThreads = 256;
-constexpr int kDeMaxPer = 1024 + 3;  // draws per update at the largest D the kernels are built for
 
 enum : uint32_t
 {
