@@ -110,10 +110,11 @@ def source_digest():
     return h.hexdigest()
 
 
-def counter_traffic(kernel):
+def counter_traffic(kernel, secondary_key=None):
     """HBM bytes per launch of `kernel` from the newest committed counter file (profiles/r*_pmc_traffic.json, written by
     tools/pmc_traffic.py from separate rocprofv3 --pmc passes of this very command) -- only if it was taken from the
-    sources this library was built from; otherwise null: a stale number is worse than none."""
+    sources this library was built from; otherwise null: a stale number is worse than none.  secondary_key: one of the
+    secondary configurations' step kernels, recorded in the same file under "secondary"."""
     import glob
     digest = source_digest()
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
@@ -121,7 +122,13 @@ def counter_traffic(kernel):
             pmc = json.load(open(path))
         except ValueError:
             continue
-        if pmc.get("source_sha256") == digest and pmc.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+        if pmc.get("source_sha256") != digest:
+            continue
+        if secondary_key is not None:
+            rec = pmc.get("secondary", {}).get(secondary_key)
+            if rec is not None and rec.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
+                return rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        elif pmc.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
             return pmc["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 
@@ -140,7 +147,7 @@ def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0
             "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch}
 
 
-def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1, mover=None):
+def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1, mover=None, traffic_key=None):
     """One of the other single-GPU configurations: runs of `batch` ensemble steps (nothing stored) for about `seconds`,
     with its roofline.  chains > 1: that many independent ensembles (seeds 0, 1, ...) stepped by the same launches."""
     if mover is None:
@@ -163,9 +170,11 @@ def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, 
     dt = time.perf_counter() - t0
     ws = float(W) * chains * batch * reps
     s.close()
+    roof = roofline_of(W, D, ws, launches, gpu_ms, kernel, rows_read=3 if mover is not None else 2)
+    if traffic_key is not None:
+        roof["traffic"], roof["traffic_source"] = counter_traffic(kernel, traffic_key)
     return {"workload": name, "walkers": W, "dims": D, "chains": chains, "value": ws / dt, "unit": "walker-steps/s",
-            "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws,
-            "roofline": roofline_of(W, D, ws, launches, gpu_ms, kernel, rows_read=3 if mover is not None else 2)}
+            "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws, "roofline": roof}
 
 
 def bench_split(args, rank, local_rank, world, dist, torch, capi):
@@ -275,6 +284,7 @@ def main():
                     help="ensemble steps of the workload timed on the CPU (about 20 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C5-ensemble secondary measurements")
+    ap.add_argument("--secondary-seconds", type=float, default=1.0, help="stepping time of each secondary configuration (counter passes use less)")
     ap.add_argument("--no-chain", action="store_true", help="experiments only: store nothing")
     ap.add_argument("--pinned-chain", action="store_true",
                     help="stored steps into a pinned block from the library (MCMCPP_CHAIN_MEMORY=pinned in the facade): the launches "
@@ -425,19 +435,19 @@ def main():
             line["secondary"] = [
                 secondary_config(capi, workloads, local_rank, "C3: 65536 walkers x 32 dims, Rosenbrock log-posterior, StretchMove, fp64; "
                                  "runs of 1000 ensemble steps, nothing stored", 65536, 32, capi.CALC_ROSENBROCK, [1.0, 100.0, 0.05],
-                                 "stretch_half_step_kernel<double, RosenbrockFn, EPL=2, LPW=16>", 1000),
+                                 "stretch_half_step_kernel<double, RosenbrockFn, EPL=2, LPW=16>", 1000, traffic_key="C3", seconds=args.secondary_seconds),
                 secondary_config(capi, workloads, local_rank, "C5's ensemble on ONE GPU: 131072 walkers x 64 dims, isotropic Gaussian, "
                                  "StretchMove, fp64; runs of 500 ensemble steps, nothing stored", 131072, 64, capi.CALC_ISO_GAUSSIAN, None,
-                                 "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>", 500),
+                                 "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>", 500, traffic_key="C5_one_gpu", seconds=args.secondary_seconds),
                 secondary_config(capi, workloads, local_rank, "C4 on ONE GPU: 8 independent chains (seeds 0..7) of 16384 walkers x 32 dims, correlated "
                                  "Gaussian, StretchMove, fp64, stepped by the same launches (mcmcpp_hip_config.num_chains = 8); runs of 2000 "
                                  "ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
-                                 "stretch_full_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>", 2000, chains=8),
+                                 "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>", 2000, chains=8, traffic_key="C4_one_gpu", seconds=args.secondary_seconds),
                 secondary_config(capi, workloads, local_rank, "C2's target under the other ensemble mover (SURVEY 8f row f3): 16384 walkers x 32 dims, "
                                  "correlated Gaussian, Mover::DifferentialEvolution, fp64; runs of 2000 ensemble steps, nothing stored; the launch "
                                  "time includes the stream-planning launches", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
-                                 "de_update_kernel<double, DenseGaussianFn, EPL=2, LPW=16> (+ de_scan_kernel, de_resolve_records_kernel)", 2000,
-                                 mover=capi.MOVER_DIFFERENTIAL_EVOLUTION),
+                                 "de_update_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16> (+ de_boundary_kernel, one per 64 half-steps)", 2000,
+                                 mover=capi.MOVER_DIFFERENTIAL_EVOLUTION, traffic_key="DE_C2", seconds=args.secondary_seconds),
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)

@@ -18,15 +18,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def mean_counter(directory, counter, kernel_sub):
+# The secondary configurations of bench.py (its `secondary` list), by the substrings their step kernel's name carries.
+SECONDARY = {
+    "C3": ["stretch_half_step_kernel<", "RosenbrockFn"],
+    "C5_one_gpu": ["stretch_half_step_kernel<", "IsoGaussianFn"],
+    "C4_one_gpu": ["stretch_half_step_mfma_kernel<", "DenseGaussianFn"],
+    "DE_C2": ["de_update_", "DenseGaussianFn"],
+}
+
+
+def mean_counter(directory, counter, kernel_sub, required=True):
+    subs = [kernel_sub] if isinstance(kernel_sub, str) else list(kernel_sub)
     vals = []
     name = None
     for path in glob.glob(directory + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and all(x in r["Kernel_Name"] for x in subs):
                 vals.append(float(r["Counter_Value"]))
                 name = r["Kernel_Name"]
     if not vals:
+        if not required:
+            return None, 0, None
         raise SystemExit("no %s rows for a kernel matching %r under %s" % (counter, kernel_sub, directory))
     return sum(vals) / len(vals), len(vals), name
 
@@ -46,6 +58,18 @@ def main():
         "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM): doubled; WRITE_SIZE exact",
         "source_sha256": bench.source_digest(),
     }
+    # the secondary configurations, when the passes ran them too (python bench.py without --no-secondary)
+    others = {}
+    for key, subs in SECONDARY.items():
+        f, n1, nm = mean_counter(fetch_dir, "FETCH_SIZE", subs, required=False)
+        w, n2, _ = mean_counter(write_dir, "WRITE_SIZE", subs, required=False)
+        if f is None or w is None:
+            continue
+        others[key] = {"kernel": nm.split("(")[0].replace("void mcmcpp::", ""), "dispatches": [n1, n2],
+                       "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w,
+                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
+    if others:
+        rec["secondary"] = others
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
