@@ -61,6 +61,36 @@ class _StdoutToStderr:
         os.close(self.saved)
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(torch, device, sysfs="/sys"):
+    """Several ranks on one node: keep this rank's threads (and so the pages of its chain block and the pinned ring its
+    GPU writes stored steps into) on the NUMA node its GPU hangs off.  Returns a note for the JSON line; any doubt (no
+    PCI address, no node, fewer than 8 permitted cores there) leaves the affinity alone."""
+    try:
+        p = torch.cuda.get_device_properties(device)
+        addr = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        node = int(open(os.path.join(sysfs, "bus/pci/devices", addr, "numa_node")).read())
+        if node < 0:
+            return "unchanged (GPU %s reports no NUMA node)" % addr
+        cpus = _parse_cpulist(open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % node)).read())
+        allowed = cpus & os.sched_getaffinity(0)
+        if len(allowed) < 8:
+            return "unchanged (%d permitted cores on NUMA node %d of GPU %s)" % (len(allowed), node, addr)
+        os.sched_setaffinity(0, allowed)
+        return "NUMA node %d of GPU %s (%d cores)" % (node, addr, len(allowed))
+    except Exception as e:  # noqa: BLE001 -- placement is an optimisation, never a reason to fail the bench
+        return "unchanged (%s: %s)" % (type(e).__name__, e)
+
+
 def cpu_baseline(W, D, P, sample_steps):
     """Time the CPU path on a bounded sample of the workload.  oracle/ is imported here and only here: as the
     measured baseline, never by the GPU path."""
@@ -247,7 +277,7 @@ def bench_split(args, rank, local_rank, world, dist, torch, capi):
                                    "enqueued by libmcmcpp_hip.so (%s); one step = %d ensemble steps"
                                    % (W, D, world, "one exchange per ensemble step, full-step kernels on the rank's slice"
                                       if per_step_launches < 1.5 else "one exchange per half-step", steps_per),
-                       "walkers": W, "dims": D, "ranks": world},
+                       "walkers": W, "dims": D, "ranks": world, "cpu_affinity_rank0": args.cpu_affinity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates,
                          "algorithmic_bytes_per_launch": updates * bytes_per_update, "avg_launch_us": kern_us,
@@ -317,6 +347,9 @@ def main():
         raise SystemExit("%d ranks but %d GPUs visible" % (world, torch.cuda.device_count()))
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
+    # (before any library thread exists: the handle's worker threads inherit the affinity)
+    want_bind = os.environ.get("MCMCPP_BENCH_NUMA_BIND", "1" if world > 1 else "0") == "1"
+    args.cpu_affinity = bind_to_gpu_numa_node(torch, local_rank) if want_bind else "unchanged (one rank, or MCMCPP_BENCH_NUMA_BIND=0)"
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -424,7 +457,7 @@ def main():
                                                        "one independent chain per GPU (seed = rank)" if world > 1
                                                        else "one chain"),
                        "walkers": W, "dims": D, "ensemble_steps_per_step": args.batch,
-                       "slicing_interval": args.interval, "chains": world,
+                       "slicing_interval": args.interval, "chains": world, "cpu_affinity_rank0": args.cpu_affinity,
                        "chain_memory": "none" if args.no_chain else ("pinned block from the library" if args.pinned_chain else "heap block (pageable)")},
             "roofline": roof,
         }

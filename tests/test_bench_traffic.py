@@ -39,3 +39,35 @@ def test_secondary_kernel_table_of_the_counter_tool():
     src = open(os.path.join(bench.ROOT, "bench.py")).read()
     for key in pmc_traffic.SECONDARY:  # every key the tool records is one bench.py asks for
         assert 'traffic_key="%s"' % key in src
+
+
+def test_numa_binding_helper(tmp_path, monkeypatch):
+    """bench.py's placement helper on a made-up sysfs tree: binds to the GPU's node when enough permitted cores live
+    there, leaves the affinity alone otherwise -- and never raises."""
+    class Props:
+        pci_domain_id, pci_bus_id, pci_device_id = 0, 0x65, 0
+
+    class Cuda:
+        @staticmethod
+        def get_device_properties(_):
+            return Props
+
+    class Torch:
+        cuda = Cuda
+
+    dev = tmp_path / "bus/pci/devices/0000:65:00.0"
+    os.makedirs(dev)
+    os.makedirs(tmp_path / "devices/system/node/node1")
+    (dev / "numa_node").write_text("1\n")
+    (tmp_path / "devices/system/node/node1/cpulist").write_text("0-3,8-15,40\n")
+    assert bench._parse_cpulist("0-3,8-15,40\n") == set(range(4)) | set(range(8, 16)) | {40}
+    bound = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(64)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda _pid, cpus: bound.append(set(cpus)))
+    note = bench.bind_to_gpu_numa_node(Torch, 0, sysfs=str(tmp_path))
+    assert bound == [set(range(4)) | set(range(8, 16)) | {40}] and note.startswith("NUMA node 1")
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: {0, 1, 2, 50})  # a container's share: too few cores on that node
+    assert bench.bind_to_gpu_numa_node(Torch, 0, sysfs=str(tmp_path)).startswith("unchanged") and len(bound) == 1
+    (dev / "numa_node").write_text("-1\n")
+    assert "no NUMA node" in bench.bind_to_gpu_numa_node(Torch, 0, sysfs=str(tmp_path))
+    assert bench.bind_to_gpu_numa_node(Torch, 0, sysfs=str(tmp_path / "nowhere")).startswith("unchanged")
