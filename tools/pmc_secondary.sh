@@ -12,3 +12,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c pass done"
 done
 python tools/pmc_traffic.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE stretch_full_step_mfma_kernel gpurun_out/pmc_traffic_$tag.json "C2 16384x32 dense Gaussian, one launch per ensemble step (python bench.py --steps 2 --warmup 1 --secondary-seconds 0.2); secondary: the step kernels of bench.py's secondary configurations in the same passes"
+{ python tools/pmc.py /tmp/pmc_${tag}_FETCH_SIZE; python tools/pmc.py /tmp/pmc_${tag}_WRITE_SIZE; } > gpurun_out/pmc_${tag}_summary.txt
