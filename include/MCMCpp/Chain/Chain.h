@@ -78,6 +78,7 @@ public:
         if (!writableStep()) return IncrementStatus::EndOfChain;
         ++stepCount;
         blocks[static_cast<std::size_t>((stepCount - 1) / stepsPerBlock)]->setUsed((stepCount - 1) % stepsPerBlock + 1);
+        if (prefetchBlocks) maybePrefetch(stepCount);
         if (stepCount >= maxSteps) return IncrementStatus::EndOfChain;
         return (stepCount % stepsPerBlock == 0) ? IncrementStatus::NewBlock : IncrementStatus::NormalIncrement;
     }
@@ -96,6 +97,12 @@ public:
             *contiguous = room;
         }
         return p;
+    }
+    /// Announce that `count` steps are about to be written at the pointer handed out by stepsContiguousFrom (a device run
+    /// in progress): lets the block behind the current one be obtained while they are being made.
+    void expectSteps(std::int64_t count)
+    {
+        if (prefetchBlocks) maybePrefetch(stepCount + count);
     }
     /// Declare `count` steps written at the pointer handed out by stepsContiguousFrom.
     void commitSteps(std::int64_t count)
@@ -119,6 +126,7 @@ public:
     {
         stepCount = 0;
         for (ChainBlock<ParamType>* b : blocks) b->setUsed(0);
+        if (nextBlock.valid()) delete nextBlock.get();  // (a block obtained ahead of a chain that starts over)
     }
 
     /// Drop `burnInSamples` leading steps, then keep every `interval`-th of the rest, compacting in place
@@ -159,6 +167,22 @@ public:
     }
 
 private:
+    /// Once the last block is half full, obtain the one behind it on a helper thread (a run that never gets that far never
+    /// pays for a block it does not use).
+    void maybePrefetch(std::int64_t stepsSoon)
+    {
+        if (nextBlock.valid() || blocks.empty()) return;
+        const std::int64_t lastLo = static_cast<std::int64_t>(blocks.size() - 1) * stepsPerBlock;
+        if (stepsSoon - lastLo < (blocks.back()->capacity() + 1) / 2) return;
+        const std::int64_t nextLo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
+        std::int64_t nextWant = stepsPerBlock;
+        if (nextLo + nextWant > maxSteps) nextWant = maxSteps - nextLo;
+        if (nextWant < 1) return;
+        const std::int64_t cells = cellsPerStep;
+        const Detail::BlockMemory mem = blockMemory;
+        nextBlock = std::async(std::launch::async, [nextWant, cells, mem]() { return new ChainBlock<ParamType>(nextWant, cells, mem, true); });
+    }
+
     /// The step being assembled (allocating its block on first use); nullptr when memory is exhausted.
     ParamType* writableStep()
     {
@@ -169,7 +193,7 @@ private:
             const std::int64_t lo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
             if (lo + want > maxSteps) want = maxSteps - lo;
             if (want < 1) return nullptr;
-            // A block is obtained one block ahead, on a thread of its own, while the sampler fills the current one: pinned
+            // A block is obtained ahead, on a thread of its own, while the sampler fills the second half of the current one: pinned
             // memory from a provider costs some 35 ms per 256 MiB block, heap memory as much in first-touch page faults
             // (which that thread takes by writing to every page).
             ChainBlock<ParamType>* nb = nullptr;
@@ -189,18 +213,6 @@ private:
                 return nullptr;
             }
             blocks.push_back(nb);
-            if (prefetchBlocks)
-            {
-                const std::int64_t nextLo = static_cast<std::int64_t>(blocks.size()) * stepsPerBlock;
-                std::int64_t nextWant = stepsPerBlock;
-                if (nextLo + nextWant > maxSteps) nextWant = maxSteps - nextLo;
-                if (nextWant >= 1)
-                {
-                    const std::int64_t cells = cellsPerStep;
-                    const Detail::BlockMemory mem = blockMemory;
-                    nextBlock = std::async(std::launch::async, [nextWant, cells, mem]() { return new ChainBlock<ParamType>(nextWant, cells, mem, true); });
-                }
-            }
         }
         return blocks[b]->step(stepCount % stepsPerBlock);
     }

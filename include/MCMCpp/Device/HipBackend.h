@@ -80,8 +80,12 @@ public:
 
     void create(const mcmcpp_hip_config& cfg)
     {
-        const int rc = mcmcpp_hip_create(&cfg, &handle);  // (the message of a failed create is kept per thread)
-        if (rc != MCMCPP_HIP_OK) die("mcmcpp_hip_create", rc, mcmcpp_hip_last_error(nullptr));
+        checkCreate("mcmcpp_hip_create", mcmcpp_hip_create(&cfg, &handle));
+    }
+    /// The same for calls that have no handle yet (the library keeps their message per thread).
+    static void checkCreate(const char* what, int rc)
+    {
+        if (rc != MCMCPP_HIP_OK) die(what, rc, mcmcpp_hip_last_error(nullptr));
     }
     /// Abort with the library's message unless rc is MCMCPP_HIP_OK.
     void check(const char* what, int rc) const

@@ -80,12 +80,7 @@ public:
         // One ensemble split over G devices: one handle per device, all ranks of one RCCL communicator.  The communicator's
         // rendezvous blocks until every rank has joined, so the handles are created concurrently.
         unsigned char commId[MCMCPP_HIP_COMM_ID_BYTES];
-        const int idrc = mcmcpp_hip_comm_unique_id(commId);
-        if (idrc != MCMCPP_HIP_OK)
-        {
-            std::fprintf(stderr, "MCMCpp (MI355X): mcmcpp_hip_comm_unique_id failed with code %d: %s\n", idrc, mcmcpp_hip_last_error(nullptr));
-            std::abort();
-        }
+        HipHandle::checkCreate("mcmcpp_hip_comm_unique_id", mcmcpp_hip_comm_unique_id(commId));
         std::vector<std::thread> joiners;
         for (int r = 0; r < G; ++r)
             joiners.push_back(std::thread([this, cfg, r, G, &where, &commId]() {
@@ -126,6 +121,7 @@ public:
             ParamType* dst = markovChain.stepsContiguousFrom(&room);
             if (!dst || room < 1) return false;
             const std::int64_t now = left < room ? left : room;
+            markovChain.expectSteps(now);
             if (stepAction == nullptr && ranks.size() == 1)
             {
                 ranks[0].check("mcmcpp_hip_run", mcmcpp_hip_run(ranks[0].get(), now, interval, dst, nullptr));

@@ -3,6 +3,7 @@ loaded, or a call fails, an exception carrying the library's own error message i
 import ctypes as C
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -135,20 +136,9 @@ def pinned_empty(shape, dtype=np.float64):
     if not p:
         raise MemoryError("mcmcpp_hip_host_alloc(%d) failed" % (n * dt.itemsize))
     buf = (C.c_char * (n * dt.itemsize)).from_address(p)
-    arr = np.frombuffer(buf, dtype=dt).reshape(shape)
-
-    class _Owner:
-        def __init__(self, p):
-            self.p = p
-
-        def __del__(self):
-            lib().mcmcpp_hip_host_free(self.p)
-
-    _PINNED_OWNERS[id(buf)] = (buf, _Owner(p))
-    return arr
-
-
-_PINNED_OWNERS = {}
+    # the memory goes back when nothing refers to the buffer any more (numpy keeps it alive through arr.base)
+    weakref.finalize(buf, lib().mcmcpp_hip_host_free, p)
+    return np.frombuffer(buf, dtype=dt).reshape(shape)
 
 
 def np_dtype(dtype):

@@ -95,8 +95,6 @@ struct Knobs
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
     long force_multi_chain_kernels; // MCMCPP_HIP_FORCE_MC                experiments: single ensembles stepped by the several-chains instantiations (0)
-    long comm_emulate_ranks;      // MCMCPP_HIP_COMM_EMULATE_RANKS       diagnostic, single-rank communicators only: step the ensemble as G slices,
-                                  //                                     one launch each, as G ranks would (tests the sliced kernels on one GPU) (1)
     static Knobs from_environment()
     {
         Knobs k;
@@ -116,7 +114,6 @@ struct Knobs
         k.copy_stream = env_long("MCMCPP_HIP_COPY_STREAM", 0);
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
-        k.comm_emulate_ranks = env_long("MCMCPP_HIP_COMM_EMULATE_RANKS", 1);
         k.force_multi_chain_kernels = env_long("MCMCPP_HIP_FORCE_MC", 0);
         return k;
     }
@@ -414,6 +411,7 @@ public:
             d_run = reinterpret_cast<RunInfo*>(piece + kRunBehindCtlBytes);
         }
         if (int rc = carve(&d_diag, sizeof(Diag))) return rc;
+        if (int rc = carve(&d_status, 8 * sizeof(uint64_t))) return rc;  // split ensembles: the status word the ranks agree on
         // the draw records (two buffers: see HalfStepArgs::draws) and, right behind them, the jump tables: one piece
         // whose layout follows from n alone (JumpTables), so that kernels reach the tables from the record pointer
         static_assert(sizeof(DrawRec<T>) == 32, "the table offsets assume 32-byte records");
@@ -497,10 +495,13 @@ public:
         // Draw records made ahead of the step launches, a batch of steps per launch (fill_draws_batch_kernel): for the
         // matrix-core full-step kernel of one whole ensemble on one device.  step_jump[j]: the draws of j ensemble steps.
         batch_draws = 0;
-        if (full_fn && full_fn == table->full_step_mc[lpw_log][epl_shift] && K == 1 && c.comm_world < 1 && whole && knobs.batch_draws != 0 && knobs.no_draw_wave == 0)
+        // (only for handles that step by graph replays: with plain launches -- the caller's legacy default stream -- every
+        //  step would drag a fill launch of its own along, and a replay's worth of record memory would sit unused)
+        if (full_fn && full_fn == table->full_step_mc[lpw_log][epl_shift] && K == 1 && c.comm_world < 1 && whole && knobs.batch_draws != 0 && knobs.no_draw_wave == 0 &&
+            graph_steps >= 1)
         {
             // (by default as many steps as a graph replays: one fill launch per replay)
-            const long want = knobs.batch_draws > 0 ? knobs.batch_draws : (graph_steps >= 1 ? (long)graph_steps : 128L);
+            const long want = knobs.batch_draws > 0 ? knobs.batch_draws : (long)graph_steps;
             batch_draws = (int)(want > 512 ? 512 : want);
             HIP_TRY(hipMalloc(&d_draws_batch, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));
             HIP_TRY(hipMemset(d_draws_batch, 0, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));  // (partner indices a kernel may follow)
@@ -822,23 +823,19 @@ public:
         return MCMCPP_HIP_OK;
     }
 
-    int run_split(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+    // Rank-local preparation of a split run: argument and state checks, staging and counter buffers.  Whatever fails here
+    // fails on this rank only -- the caller agrees on it with the other ranks (agree_on_status) before the first launch.
+    int prepare_split(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step, int64_t* stage_slots_out)
     {
         if (!have_state) return fail(MCMCPP_HIP_E_STATE, "run: set_state has not been called");
         if (n_saved < 0 || interval < 1) return fail(MCMCPP_HIP_E_ARG, "run: n_saved >= 0 and interval >= 1 required");
         if (half_steps & 1) return fail(MCMCPP_HIP_E_STATE, "run: an ensemble step is half done (half_step_async)");
         HIP_TRY(hipSetDevice(device));
         const int64_t total = n_saved * (int64_t)interval;
-        last_ms = 0.0;
-        last_launches = 0;
-        host_enqueue_ms = host_wall_ms = exchange_us_per_step = 0.0;
-        if (total == 0) return MCMCPP_HIP_OK;
-        const auto tp0 = std::chrono::steady_clock::now();
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
-
         // stored steps: device -> pinned staging on the launch stream, handed to the caller a staging buffer at a time
         int64_t stage_slots = 0;
-        if (chain_out)
+        if (chain_out && total > 0)
         {
             stage_slots = (int64_t)(((size_t)256 << 20) / step_bytes);
             if (stage_slots < 1) stage_slots = 1;
@@ -850,18 +847,65 @@ public:
                 h_split_stage = nullptr;
                 split_stage_capacity = 0;
                 if (hipHostMalloc(&h_split_stage, step_bytes * (size_t)stage_slots, hipHostMallocDefault) != hipSuccess)
+                {
+                    (void)hipGetLastError();
                     return fail(MCMCPP_HIP_E_NOMEM, "run: cannot allocate %zu bytes of pinned staging", step_bytes * (size_t)stage_slots);
+                }
                 split_stage_capacity = step_bytes * (size_t)stage_slots;
             }
         }
-        int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, 0, 0);
+        *stage_slots_out = stage_slots;
+        const int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, 0, 0);
         if (rc) return rc;
-        constexpr int kMaxSamples = 32;
         if (ev_x.empty())
         {
-            ev_x.assign(2 * kMaxSamples, nullptr);
+            ev_x.assign(2 * kMaxExchangeSamples, nullptr);
             for (hipEvent_t& e : ev_x) HIP_TRY(hipEventCreate(&e));
         }
+        return MCMCPP_HIP_OK;
+    }
+
+    // Every rank learns the worst status among the ranks (and that all were asked for the same number of steps) before any
+    // of them launches or exchanges anything: a rank that failed its preparation would otherwise leave the others waiting
+    // in their first all-gather for good.  One small all-reduce and one stream synchronisation per run.
+    int agree_on_status(int local_rc, int64_t total)
+    {
+        uint64_t* hs = reinterpret_cast<uint64_t*>(h_pinned);  // [0, 64): words out, [64, 128): words back
+        hs[0] = (uint64_t)local_rc;
+        hs[1] = (uint64_t)total;
+        hs[2] = ~(uint64_t)total;
+        const std::string mine = error;
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipMemcpyAsync(d_status, hs, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        NCCL_TRY(rccl->AllReduce(d_status, d_status, 3, ncclUint64, ncclMax, comm, stream));
+        HIP_TRY(hipMemcpyAsync(hs + 8, d_status, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (local_rc != MCMCPP_HIP_OK)
+        {
+            error = mine;
+            return local_rc;
+        }
+        if (hs[8] != 0) return fail((int)hs[8], "run: the preparation of another rank of the split ensemble failed (code %d); nothing was launched", (int)hs[8]);
+        if (hs[9] != ~hs[10]) return fail(MCMCPP_HIP_E_ARG, "run: the ranks of the split ensemble were asked for different numbers of steps; nothing was launched");
+        return MCMCPP_HIP_OK;
+    }
+
+    static constexpr int kMaxExchangeSamples = 32;
+
+    int run_split(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
+    {
+        last_ms = 0.0;
+        last_launches = 0;
+        host_enqueue_ms = host_wall_ms = exchange_us_per_step = 0.0;
+        const auto tp0 = std::chrono::steady_clock::now();
+        int64_t stage_slots = 0;
+        const int prep = prepare_split(n_saved, interval, chain_out, accepted_per_step, &stage_slots);
+        const int64_t total = (n_saved > 0 && interval > 0) ? n_saved * (int64_t)interval : 0;
+        int rc = agree_on_status(prep, total);
+        if (rc) return rc;
+        if (total == 0) return MCMCPP_HIP_OK;
+        const size_t step_bytes = sizeof(T) * (size_t)W * D;
+        constexpr int kMaxSamples = kMaxExchangeSamples;
         if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         run_touched_device = true;
         rc = write_ctl(0);
@@ -895,18 +939,6 @@ public:
         fill_red.shard_begin = 0;
         fill_red.shard_count = n;
 
-        // diagnostic (MCMCPP_HIP_COMM_EMULATE_RANKS = G, single-rank communicators): the slices of G ranks, one launch each
-        int emu = (int)knobs.comm_emulate_ranks;
-        if (emu < 1 || cfg.comm_world != 1 || shard_count % emu != 0) emu = 1;
-        const int emu_count = shard_count / emu;
-        const int emu_waves = (int)(full_fn ? full_grid_blocks_for(emu_count) : grid_blocks_for(emu_count)) * kWavesPerBlock;
-        if ((long)emu_waves * emu > partial_waves) emu = 1;
-        auto slice = [&](HalfStepArgs<T>& a, int r) {
-            a.shard_begin = shard_begin + r * (emu > 1 ? emu_count : 0);
-            a.shard_count = emu > 1 ? emu_count : shard_count;
-            a.partials = d_partials + (size_t)r * (emu > 1 ? emu_waves : 0);
-        };
-
         const int64_t sample_stride = total > kMaxSamples ? total / kMaxSamples : 1;
         int samples = 0, unreduced = 0;
         int64_t staged = 0, handed = 0;  // stored steps copied to staging / handed to the caller
@@ -928,11 +960,7 @@ public:
             {
                 fill_red.draw_parity = parity;
                 launch_fill_draws(fill_red, red_base, nullptr, stream);
-                for (int r = 0; r < emu; ++r)
-                {
-                    slice(args_red, r);
-                    enqueue_step(parity, pos_parity);
-                }
+                enqueue_step(parity, pos_parity);
                 // (the per-wavefront accepted counts are summed once per partial_slots steps, and at the end of the run)
                 if (++unreduced == partial_slots || s + 1 == total)
                 {
@@ -952,21 +980,13 @@ public:
             {
                 args_red.draw_parity = parity;
                 args_blk.draw_parity = parity;
-                for (int r = 0; r < emu; ++r)
-                {
-                    slice(args_red, r);
-                    half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
-                }
+                half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
                 HIP_TRY(hipGetLastError());
                 if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
                 rc = exchange_rows(d_pos, nullptr, 0, 1);
                 if (rc) return rc;
                 if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
-                for (int r = 0; r < emu; ++r)
-                {
-                    slice(args_blk, r);
-                    half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
-                }
+                half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
                 if (++unreduced == partial_slots || s + 1 == total)
                 {
                     launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
@@ -1724,6 +1744,7 @@ private:
     StepCtl* d_ctl = nullptr;
     RunInfo* d_run = nullptr;
     Diag* d_diag = nullptr;
+    uint64_t* d_status = nullptr;
     DrawRec<T>* d_draws = nullptr;
     DrawRec<T>* d_draws_batch = nullptr;  // [batch_draws][2][n]: records made ahead of the matrix-core full-step launches
     Affine128* d_step_jump = nullptr;     // [batch_draws]
@@ -1883,27 +1904,45 @@ int mcmcpp_hip_create(const mcmcpp_hip_config* cfg, mcmcpp_hip_sampler** out)
     return MCMCPP_HIP_OK;
 }
 
-void mcmcpp_hip_destroy(mcmcpp_hip_sampler* h) { delete h; }
+void mcmcpp_hip_destroy(mcmcpp_hip_sampler* h)
+{
+    if (!h) return;
+    // an asynchronous run still uses the arena, streams, graphs and the communicator the destructor releases: let it end first
+    if (h->async_worker.joinable()) h->async_worker.join();
+    h->async_active = false;
+    delete h;
+}
 
-const char* mcmcpp_hip_last_error(const mcmcpp_hip_sampler* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+const char* mcmcpp_hip_last_error(const mcmcpp_hip_sampler* h)
+{
+    if (!h) return g_create_error.c_str();
+    return h->refused ? h->refused : h->error.c_str();
+}
 
 #define NEED_H \
     if (!h) return MCMCPP_HIP_E_ARG
+// between run_async and run_wait the handle belongs to its worker thread: only wait_stored (and destroy, which joins) may be called
+#define NOT_WHILE_ASYNC(name) \
+    if (h->async_active) return h->refuse("mcmcpp_hip_" name ": an asynchronous run is in progress (only wait_stored may be called before run_wait)"); \
+    h->refused = nullptr
 
 int mcmcpp_hip_set_state(mcmcpp_hip_sampler* h, const void* positions, const void* logp)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("set_state");
     return h->set_state(positions, logp);
 }
 int mcmcpp_hip_run(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("run");
     return h->run(n_saved, interval, chain_out, accepted_per_step);
 }
 int mcmcpp_hip_run_async(mcmcpp_hip_sampler* h, int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
 {
     NEED_H;
-    if (h->async_active) return h->fail(MCMCPP_HIP_E_STATE, "run_async: the previous asynchronous run has not been waited for (mcmcpp_hip_run_wait)");
+    if (h->async_active) return h->refuse("mcmcpp_hip_run_async: the previous asynchronous run has not been waited for (mcmcpp_hip_run_wait)");
+    h->refused = nullptr;
     {
         std::lock_guard<std::mutex> lock(h->async_mutex);
         h->async_stored = 0;
@@ -1947,12 +1986,15 @@ int mcmcpp_hip_run_wait(mcmcpp_hip_sampler* h)
     if (!h->async_active) return h->fail(MCMCPP_HIP_E_STATE, "run_wait: no asynchronous run in progress");
     if (h->async_worker.joinable()) h->async_worker.join();
     h->async_active = false;
+    h->refused = nullptr;
     return h->async_rc;
 }
 void* mcmcpp_hip_host_alloc(uint64_t bytes)
 {
     void* p = nullptr;
-    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 64, hipHostMallocDefault) != hipSuccess)
+    // (portable: usable from every device of the process, whichever one happens to be current on the calling thread --
+    //  the facade's Chain obtains blocks on a helper thread that has never selected a device)
+    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 64, hipHostMallocPortable) != hipSuccess)
     {
         (void)hipGetLastError();
         return nullptr;
@@ -1966,27 +2008,32 @@ void mcmcpp_hip_host_free(void* p)
 int mcmcpp_hip_get_state(mcmcpp_hip_sampler* h, void* positions, void* logp, uint32_t* n_accept)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("get_state");
     return h->get_state(positions, logp, n_accept);
 }
 int mcmcpp_hip_seek(mcmcpp_hip_sampler* h, uint64_t ensemble_steps_done)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("seek");
     return h->seek(ensemble_steps_done);
 }
 int mcmcpp_hip_reset_counters(mcmcpp_hip_sampler* h)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("reset_counters");
     return h->reset_counters();
 }
 int mcmcpp_hip_get_counters(mcmcpp_hip_sampler* h, uint64_t* accepted, uint64_t* ensemble_steps, uint64_t* near_ties,
                             uint64_t* redraws)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("get_counters");
     return h->get_counters(accepted, ensemble_steps, near_ties, redraws);
 }
 int mcmcpp_hip_calc_logp(mcmcpp_hip_sampler* h, const void* positions, int64_t count, void* logp_out)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("calc_logp");
     return h->calc_logp(positions, count, logp_out);
 }
 int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* step_launches)
@@ -2029,22 +2076,26 @@ int mcmcpp_hip_comm_unique_id(void* id_out)
 int mcmcpp_hip_half_step_async(mcmcpp_hip_sampler* h, int32_t color, int64_t save_slot)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("half_step_async");
     return h->half_step_async(color, save_slot);
 }
 int mcmcpp_hip_bind_device_chain(mcmcpp_hip_sampler* h, void* device_chain, int64_t slots)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("bind_device_chain");
     return h->bind_device_chain(device_chain, slots);
 }
 void* mcmcpp_hip_device_positions(mcmcpp_hip_sampler* h) { return h ? h->device_positions() : nullptr; }
 int mcmcpp_hip_shard_span(mcmcpp_hip_sampler* h, int32_t color, int64_t* offset_elems, int64_t* count_elems)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("shard_span");
     return h->shard_span(color, offset_elems, count_elems);
 }
 int mcmcpp_hip_synchronize(mcmcpp_hip_sampler* h)
 {
     NEED_H;
+    NOT_WHILE_ASYNC("synchronize");
     return h->synchronize();
 }
 }

@@ -55,6 +55,15 @@ struct mcmcpp_hip_sampler
     virtual int synchronize() = 0;
     virtual int debug_stamps(unsigned long long* out8) = 0;
 
+    // A call refused because the handle is busy with an asynchronous run: the message is a literal kept beside `error`,
+    // which belongs to the worker thread while it runs (only the caller's thread touches `refused`).
+    const char* refused = nullptr;
+    int refuse(const char* literal)
+    {
+        refused = literal;
+        return MCMCPP_HIP_E_STATE;
+    }
+
     int fail(int code, const char* fmt, ...)
     {
         char buf[512];

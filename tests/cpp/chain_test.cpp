@@ -187,17 +187,23 @@ int main()
         }
         CHECK(ProviderCalls::released == 3);  // (heap blocks are not handed to the provider's release)
         ProviderCalls::fail = false;
-        // blocks obtained one ahead on a helper thread (what the samplers switch on): same contents; a block that was
-        // obtained ahead and never used is returned when the chain goes
+        // blocks obtained ahead on a helper thread once the current one is half full (what the samplers switch on): same
+        // contents; a block that was obtained ahead and never used is returned when the chain goes (or starts over)
         ProviderCalls::obtained = ProviderCalls::released = 0;
         {
             ChainD c(W, D, 12 * stepBytes, 4 * stepBytes, MCMC::Chain::Detail::BlockMemory(&ProviderCalls::obtain, &ProviderCalls::release));
             c.setBlockPrefetch(true);
-            fill(c, 5, W, D);
+            fill(c, 5, W, D);  // the second block holds one step of four: nothing is obtained behind it yet
+            CHECK(ProviderCalls::obtained == 2);
+            fill(c, 2, W, D, 5);
             long s = 0;
             for (MCMC::Chain::ChainStepIterator<double> it = c.getStepIteratorBegin(); it != c.getStepIteratorEnd(); ++it, ++s)
                 CHECK((*it)[W * D - 1] == cell(s, W - 1, D - 1));
-            CHECK(s == 5);
+            CHECK(s == 7);
+            c.resetChain();  // the third block was obtained ahead and goes back; the two in use stay
+            CHECK(ProviderCalls::obtained == 3 && ProviderCalls::released == 1);
+            c.expectSteps(3);  // a device run about to write three steps: the second block is not the last one in use
+            CHECK(ProviderCalls::obtained == 3);
         }
         CHECK(ProviderCalls::obtained == 3 && ProviderCalls::released == 3);
         {

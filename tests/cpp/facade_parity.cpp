@@ -211,6 +211,29 @@ static void runCase(const Fixture<T>& f, Calc calc)
         sampler.diagnostics(&ties, &redraws);
         CHECK(ties == 0 && redraws == 0);
     }
+    if (!Sel::drawsVary && std::getenv("FACADE_PARITY_PLACEMENT_RANKS"))
+    {
+        // one ensemble split over several ranks named by an explicit placement (tests/test_split_loopback.py: all on device 0,
+        // exchanging through the loop-back collective library), with a PostStepAction watching the chain
+        const int G = std::atoi(std::getenv("FACADE_PARITY_PLACEMENT_RANKS"));
+        MoverType mover(f.D, 0, calc);
+        CountingAction<T> action;
+        Device::Placement where(std::vector<int>((size_t)G, 0));
+        ParallelEnsembleSampler<T, MoverType, CountingAction<T> > sampler(0, 8, f.W, f.D, mover, 2147483648ULL, &action, where);
+        CHECK(sampler.deviceCount() == G);
+        sampler.setSamplingMode(f.slicing, 0);
+        sampler.setInitialWalkerPos(pos.data(), logp.data());
+        CHECK(sampler.runMCMC(f.steps / 3));
+        CHECK(sampler.runMCMC(f.steps - f.steps / 3));
+        checkChain(sampler, f);
+        CHECK(sampler.getAcceptedSteps() == f.acceptedTotal);
+        CHECK(sampler.getAcceptanceFraction() == (T)f.acceptedTotal / (T)f.totalSteps);
+        CHECK(action.calls == (long)f.steps * f.slicing);
+        std::uint64_t ties = 1, redraws = 1;
+        sampler.diagnostics(&ties, &redraws);
+        CHECK(ties == 0 && redraws == 0);
+        std::printf("placement of %d ranks checked\n", G);
+    }
     {
         // chain budget: room for 5 steps only -> runMCMC reports false when it fills (EnsembleSampler.h:293)
         MoverType mover(f.D, 0, calc);

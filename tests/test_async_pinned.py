@@ -79,3 +79,30 @@ def test_async_run_reports_a_failed_run():
         hip.wait_stored(1)
     with pytest.raises(capi.HipError):
         hip.run_wait()
+
+
+@pytest.mark.parametrize("mover", [capi.MOVER_STRETCH, capi.MOVER_DIFFERENTIAL_EVOLUTION])
+def test_handle_belongs_to_its_worker_between_run_async_and_run_wait(mover):
+    """Between run_async and run_wait only wait_stored is allowed: every other entry point is refused (E_STATE) instead
+    of racing with the worker, and destroying the handle first lets the run end (the worker uses the arena, streams and
+    graphs the destructor frees)."""
+    W, D = 16384, 32
+    pos = po.init_positions(po.F64, W, D, salt=2)
+    hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=4, mover=mover)
+    hip.set_state(pos, hip.calc_logp(pos))
+    chain, _ = hip.run_async(4, interval=500)
+    for call in (lambda: hip.run(1), lambda: hip.get_state(), lambda: hip.set_state(pos, np.zeros(W)), lambda: hip.reset_counters(),
+                 lambda: hip.counters(), lambda: hip.seek(0), lambda: hip.calc_logp(pos), lambda: hip.synchronize(),
+                 lambda: hip.run_async(1)):
+        with pytest.raises(capi.HipError) as e:
+            call()
+        assert e.value.code == 5 and "asynchronous run" in str(e.value)
+    hip.wait_stored(1)
+    hip.run_wait()
+    first = chain.copy()
+    assert hip.counters()["ensemble_steps"] == 2000
+    # the same run again from the same state; this time the handle is destroyed while the worker is stepping
+    hip.set_state(pos, hip.calc_logp(pos))
+    again, _ = hip.run_async(4, interval=500)
+    hip.close()  # joins the worker, then frees
+    np.testing.assert_array_equal(again, first)

@@ -76,14 +76,11 @@ def _params(calc, D, rng):
 @pytest.mark.parametrize("W,D,calc", [(4096, 32, po.CALC_ISO_GAUSSIAN), (4096, 32, po.CALC_DENSE_GAUSSIAN), (2048, 64, po.CALC_DENSE_GAUSSIAN),
                                       (1024, 7, po.CALC_ROSENBROCK)])
 @pytest.mark.parametrize("scheme", ["exchange_per_step", "exchange_per_half_step"])
-@pytest.mark.parametrize("slices", [1, 4])
-def test_split_ensemble_run_through_the_c_abi(monkeypatch, W, D, calc, scheme, slices):
-    """mcmcpp_hip_run on a handle with an RCCL communicator (one rank: all this box has): launches and ncclAllGather
-    calls enqueued by the library itself, stored steps, ensemble-wide accepted counts, get_state -- bit for bit the
-    oracle's chain.  `slices` > 1 steps the ensemble as that many ranks' slices, one launch each (the sliced kernels of
-    both schemes: a black walker's group repeating a red update that another rank owns)."""
+def test_split_ensemble_run_through_the_c_abi(monkeypatch, W, D, calc, scheme):
+    """mcmcpp_hip_run on a handle with a REAL RCCL communicator (one rank: all this box has): launches and ncclAllGather /
+    ncclAllReduce calls enqueued by the library itself, stored steps, ensemble-wide accepted counts, get_state -- bit for
+    bit the oracle's chain.  More than one rank (sliced kernels, exchange offsets): tests/test_split_loopback.py."""
     monkeypatch.setenv("MCMCPP_HIP_COMM_FULL_STEP", "1" if scheme == "exchange_per_step" else "0")
-    monkeypatch.setenv("MCMCPP_HIP_COMM_EMULATE_RANKS", str(slices))
     rng = np.random.default_rng(11)
     params = _params(calc, D, rng)
     orc = po.Oracle(W, D, calc, params, seed=9)
@@ -118,30 +115,23 @@ def test_split_ensemble_config_is_checked():
 
 
 def test_config5_full_size_split_run_single_rank():
-    """BASELINE config 5's ensemble (131 072 x 64) through the split path of the C ABI on the one GPU this box has:
-    3 steps against the multi-threaded oracle (half-step scheme: the slice is the whole half), then as 8 ranks'
-    slices of 8 192 walkers per colour -- the per-GPU launches of the 8-GPU job, one exchange per ensemble step."""
+    """BASELINE config 5's ensemble (131 072 x 64) through the split path of the C ABI with one rank of a real RCCL
+    communicator: 3 steps against the multi-threaded oracle (half-step scheme: the slice is the whole half).  Eight
+    ranks of 8 192 walkers per colour: tests/test_split_loopback.py."""
     W, D = 131072, 64
     orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=0)
     pos = po.init_positions(po.F64, W, D, salt=0)
     logp = orc.logp(pos)
     orc.set_state(pos, logp)
     want_chain, want_acc = orc.run(3, mode=po.MODE_COUNTER, threads=8)
-    for env in ({}, {"MCMCPP_HIP_COMM_EMULATE_RANKS": "8", "MCMCPP_HIP_FULL_STEP_MAX_WALKERS": "262144"}):
-        for k, v in env.items():
-            os.environ[k] = v
-        try:
-            hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, comm_world=1, comm_rank=0, comm_id=capi.comm_unique_id())
-        finally:
-            for k in env:
-                del os.environ[k]
-        hip.set_state(pos, logp)
-        chain, acc = hip.run(3)
-        np.testing.assert_array_equal(acc, want_acc)
-        np.testing.assert_array_equal(chain, want_chain)
-        for got, want in zip(hip.get_state(), orc.get_state()):
-            np.testing.assert_array_equal(got, want)
-        hip.close()
+    hip = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, comm_world=1, comm_rank=0, comm_id=capi.comm_unique_id())
+    hip.set_state(pos, logp)
+    chain, acc = hip.run(3)
+    np.testing.assert_array_equal(acc, want_acc)
+    np.testing.assert_array_equal(chain, want_chain)
+    for got, want in zip(hip.get_state(), orc.get_state()):
+        np.testing.assert_array_equal(got, want)
+    hip.close()
 
 
 def test_whole_ensemble_handle_on_the_legacy_default_stream():
