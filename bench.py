@@ -207,94 +207,166 @@ def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, 
             "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws, "roofline": roof}
 
 
-def bench_split(args, rank, local_rank, world, dist, torch, capi):
+LOOPBACK_LIB = os.path.join(ROOT, "tests", "cpp", "_build", "libloopback_ccl.so")
+
+
+def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, warmup, loopback_ranks=0):
     """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling.
-    Every rank owns one handle with an RCCL communicator: mcmcpp_hip_run enqueues the step launches and the exchanges."""
+    Every rank owns one handle with an RCCL communicator: mcmcpp_hip_run enqueues the step launches and the exchanges.
+    Returns the measurement (rank 0; None elsewhere).
+
+    loopback_ranks = G > 0 (rehearsals on a one-GPU box; MCMCPP_HIP_RCCL_LIB must name tests/cpp/loopback_ccl's library before
+    the library binds its collectives): G ranks as G threads of THIS process, all on this process's GPU -- the product's
+    world > 1 code with a loop-back exchange; throughput figures then describe G ranks sharing one GPU, not a G-GPU job."""
+    import threading
     from mcmcpp_amd import workloads
     W, D = args.split_walkers, 64
     steps_per = 50
+    G = loopback_ranks if loopback_ranks > 0 else world
     with _StdoutToStderr():  # (RCCL's banner)
-        if world > 1:
+        if world > 1 and loopback_ranks == 0:
             box = [capi.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             cid = box[0]
         else:
             cid = capi.comm_unique_id()
-        ens = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, device=local_rank, comm_world=world, comm_rank=rank,
-                              comm_id=cid)
     pos = workloads.init_positions(W, D, salt=0)
-    logp = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank).calc_logp(pos)
-    ens.set_state(pos, logp)
-    for _ in range(args.warmup):
-        ens.run(1, interval=steps_per, save_chain=False)
+    probe = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank)
+    logp = probe.calc_logp(pos)
+    probe.close()
 
-    def barrier():
-        if dist is not None:
+    def outer_barrier():
+        if dist is not None and loopback_ranks == 0:
             dist.barrier()
         torch.cuda.synchronize()
 
-    accepted, gpu_ms, launches, enq_ms, xchg_us = 0, 0.0, 0, 0.0, 0.0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, acc = ens.run(1, interval=steps_per, save_chain=False)
-        accepted += int(acc.sum())  # (ensemble-wide counts: all-reduced by the library)
-        ms, nl = ens.last_run_timing()
-        gpu_ms += ms
-        launches += nl
-        e, _, x = ens.last_run_host_timing()
-        enq_ms += e
-        xchg_us += x
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
+    thread_barrier = threading.Barrier(G) if loopback_ranks > 0 else None
+    results = {}
+
+    def one_rank(r):
+        with (_Nothing() if loopback_ranks > 0 else _StdoutToStderr()):
+            ens = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, device=local_rank, comm_world=G, comm_rank=r, comm_id=cid)
+        ens.set_state(pos, logp)
+        for _ in range(warmup):
+            ens.run(1, interval=steps_per, save_chain=False)
+        accepted, gpu_ms, launches, enq_ms, xchg_us, xbytes, repeats, slots = 0, 0.0, 0, 0.0, 0.0, 0.0, 0, 0
+        if thread_barrier is not None:
+            thread_barrier.wait()
+        else:
+            outer_barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, acc = ens.run(1, interval=steps_per, save_chain=False)
+            accepted += int(acc.sum())  # (ensemble-wide counts: all-reduced by the library)
+            ms, nl = ens.last_run_timing()
+            gpu_ms += ms
+            launches += nl
+            e, _, x = ens.last_run_host_timing()
+            enq_ms += e
+            xchg_us += x
+            b, rp, sl = ens.last_run_exchange()
+            xbytes += b
+            repeats += rp
+            slots = sl
+        if thread_barrier is not None:
+            thread_barrier.wait()
+        else:
+            outer_barrier()
+        results[r] = dict(elapsed=time.perf_counter() - t0, accepted=accepted, gpu_ms=gpu_ms, launches=launches, enq_ms=enq_ms,
+                          xchg_us=xchg_us, xbytes=xbytes / steps, repeats=repeats, slots=slots)
+        ens.close()
+
+    if loopback_ranks > 0:
+        errs = []
+
+        def guarded(r):
+            try:
+                one_rank(r)
+            except Exception as e:  # noqa: BLE001
+                errs.append("rank %d: %s" % (r, e))
+                if thread_barrier is not None:
+                    thread_barrier.abort()
+        threads = [threading.Thread(target=guarded, args=(r,)) for r in range(G)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise RuntimeError("; ".join(errs))
+        mine = results[0]
+    else:
+        one_rank(rank)
+        mine = results[rank]
+    elapsed = mine["elapsed"]
+    if dist is not None and loopback_ranks == 0:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_steps = steps_per * args.steps
+    if rank != 0:
+        return None
+    n_steps = steps_per * steps
     total = float(W) * n_steps
+    launches, gpu_ms = mine["launches"], mine["gpu_ms"]
+    per_step_launches = launches / n_steps  # 1: one exchange per ensemble step; 2: one per half-step
+    whole = W * D * 8 * (G - 1) / G  # position bytes a rank receives per ensemble step when whole slices are all-gathered
+    recv = mine["xbytes"]
+    xchg = mine["xchg_us"] / steps
+    # what one rank updates per launch: its slice of one colour (half-step kernels) or of both (full-step kernels)
+    updates = float(W) / G / (2 if per_step_launches > 1.5 else 1)
+    kernel = ("stretch_full_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>" if per_step_launches < 1.5 else
+              "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>")
+    step_us = gpu_ms * 1e3 / n_steps  # GPU time of one ensemble step on the launch stream: kernels + exchange
+    # per launch, between several ranks without the sampled exchange time; a single rank's "exchange" moves nothing and
+    # its events only bracket launch gaps, so there the whole stream time is charged to the launches
+    kern_us = (max(step_us - xchg, 1e-9) if G > 1 else step_us) / per_step_launches
+    bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
+    achieved = updates * bytes_per_update / (kern_us * 1e-6) / 1e9
+    how = ("%d GPU(s)" % world) if loopback_ranks == 0 else ("%d ranks as threads of one process on ONE GPU, exchanging through the test-only "
+                                                              "loop-back collective library (a rehearsal of the code path, not a %d-GPU measurement)" % (G, G))
+    return {
+        "metric": "walker-steps/sec + acceptance rate, 131072 walkers x 64 dims split over the GPUs",
+        "value": total / elapsed, "unit": "walker-steps/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "acceptance_rate": mine["accepted"] / total,
+        "config": {"workload": "C5: one %dx%d isotropic-Gaussian ensemble split over %s; launches and exchanges "
+                               "enqueued by libmcmcpp_hip.so (%s); one step = %d ensemble steps"
+                               % (W, D, how, "one exchange per ensemble step, full-step kernels on the rank's slice"
+                                  if per_step_launches < 1.5 else "one exchange per half-step", steps_per),
+                   "walkers": W, "dims": D, "ranks": G, "cpu_affinity_rank0": args.cpu_affinity},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates,
+                     "algorithmic_bytes_per_launch": updates * bytes_per_update, "avg_launch_us": kern_us,
+                     "note": "per rank; launch time = (stream time of a step - sampled exchange time) / launches per step; with one "
+                             "rank the exchange calls are charged to the launches"},
+        "allgather": {"bytes_received_per_rank_per_step": recv, "bytes_if_whole_slices_were_gathered": whole,
+                      "block_slots": mine["slots"], "repeated_chunks": mine["repeats"],
+                      "exchange_us_per_step": xchg,
+                      "gb_per_s_per_rank": (recv / (xchg * 1e-6) / 1e9) if xchg > 0 and G > 1 else None,
+                      "gb_per_s_per_link": (recv / (G - 1) / (xchg * 1e-6) / 1e9) if xchg > 0 and G > 1 else None,
+                      "link_peak_gb_per_s": 153.0,
+                      "note": "ranks of more than one exchange only the rows that moved (mcmcpp_hip_last_run_exchange: packed blocks, one "
+                              "all-gather per exchange, scatter; block_slots = walkers per block learned from the run, 0 = whole slices); "
+                              "exchange time = HIP events around a sample of exchanges (pack + all-gather + scatter) on the launch stream; "
+                              "a single rank moves nothing (rates null)"},
+        "host": {"enqueue_us_per_step": mine["enq_ms"] * 1e3 / n_steps, "gpu_us_per_step": step_us,
+                 "note": "time the host thread spends enqueueing one ensemble step (launches + exchange calls) against the "
+                         "GPU time of that step: the host must stay below it"},
+    }
+
+
+class _Nothing:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def bench_split(args, rank, local_rank, world, dist, torch, capi):
+    line = split_measurement(args, rank, local_rank, world, dist, torch, capi, args.steps, args.warmup, loopback_ranks=args.loopback_ranks)
     if rank == 0:
-        per_step_launches = launches / n_steps  # 1: one exchange per ensemble step; 2: one per half-step
-        recv = W * D * 8 * (world - 1) / world  # position bytes each rank receives per ensemble step
-        xchg = xchg_us / args.steps
-        # what one rank updates per launch: its slice of one colour (half-step kernels) or of both (full-step kernels)
-        updates = float(W) / world / (2 if per_step_launches > 1.5 else 1)
-        kernel = ("stretch_full_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>" if per_step_launches < 1.5 else
-                  "stretch_half_step_kernel<double, IsoGaussianFn, EPL=2, LPW=32>")
-        step_us = gpu_ms * 1e3 / n_steps  # GPU time of one ensemble step on the launch stream: kernels + exchange
-        # per launch, between several ranks without the sampled exchange time; a single rank's "exchange" moves nothing and
-        # its events only bracket launch gaps, so there the whole stream time is charged to the launches
-        kern_us = (max(step_us - xchg, 1e-9) if world > 1 else step_us) / per_step_launches
-        bytes_per_update = (2 * D + 1) * 8 + (D + 1) * 8
-        achieved = updates * bytes_per_update / (kern_us * 1e-6) / 1e9
-        line = {
-            "metric": "walker-steps/sec + acceptance rate, 131072 walkers x 64 dims split over the GPUs",
-            "value": total / elapsed, "unit": "walker-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "acceptance_rate": accepted / total,
-            "config": {"workload": "C5: one %dx%d isotropic-Gaussian ensemble split over %d GPU(s); launches and RCCL all-gathers "
-                                   "enqueued by libmcmcpp_hip.so (%s); one step = %d ensemble steps"
-                                   % (W, D, world, "one exchange per ensemble step, full-step kernels on the rank's slice"
-                                      if per_step_launches < 1.5 else "one exchange per half-step", steps_per),
-                       "walkers": W, "dims": D, "ranks": world, "cpu_affinity_rank0": args.cpu_affinity},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates,
-                         "algorithmic_bytes_per_launch": updates * bytes_per_update, "avg_launch_us": kern_us,
-                         "note": "per rank; launch time = (stream time of a step - sampled exchange time) / launches per step; with one "
-                                 "rank the exchange calls are charged to the launches"},
-            "allgather": {"bytes_received_per_rank_per_step": recv, "exchange_us_per_step": xchg,
-                          "gb_per_s_per_rank": (recv / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,
-                          "gb_per_s_per_link": (recv / (world - 1) / (xchg * 1e-6) / 1e9) if xchg > 0 and world > 1 else None,
-                          "link_peak_gb_per_s": 153.0,
-                          "note": "exchange time = HIP events around a sample of exchanges on the launch stream; a single rank "
-                                  "moves nothing (rates null)"},
-            "host": {"enqueue_us_per_step": enq_ms * 1e3 / n_steps, "gpu_us_per_step": step_us,
-                     "note": "time the host thread spends enqueueing one ensemble step (launches + exchange calls) against the "
-                             "GPU time of that step: the host must stay below it"},
-        }
         print(json.dumps(line), flush=True)
-    ens.close()
     if dist is not None:
         dist.destroy_process_group()
 
@@ -325,11 +397,22 @@ def main():
                          "one 131072x64 ensemble split over the GPUs, exchanged over RCCL by the library")
     ap.add_argument("--split-walkers", type=int, default=131072,
                     help="--mode split: walkers of the ensemble (16384 on one GPU = what one rank of the 8-GPU job updates)")
+    ap.add_argument("--loopback-ranks", type=int, default=0,
+                    help="--mode split on ONE GPU: that many ranks as threads of this process, exchanging through the test-only loop-back "
+                         "collective library (tests/cpp/loopback_ccl.hip) -- a rehearsal of the world > 1 code path")
+    ap.add_argument("--no-split-leg", action="store_true", help="several ranks: skip the bounded C5 (split ensemble) measurement behind the chains")
+    ap.add_argument("--split-leg-seconds", type=float, default=20.0, help="several ranks: time limit of that measurement")
     ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
                     help="experiments only: the headline workload is the dense (correlated) Gaussian")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 20 if args.mode == "split" else 500
+
+    if args.loopback_ranks > 0 or os.environ.get("MCMCPP_BENCH_SPLIT_LEG") == "loopback":
+        # (before the library binds its collectives, i.e. before the first handle with a communicator)
+        if not os.path.exists(LOOPBACK_LIB):
+            raise SystemExit("%s is missing: python -m pytest tests/test_split_loopback.py -k exports builds it" % LOOPBACK_LIB)
+        os.environ["MCMCPP_HIP_RCCL_LIB"] = LOOPBACK_LIB
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -416,6 +499,13 @@ def main():
 
     from mcmcpp_amd import distributed as md
     walker_steps = float(W) * args.batch * args.steps
+    per_rank_values = None
+    if dist is not None:
+        # every rank's own throughput beside the aggregate (the aggregate divides by the slowest rank's time)
+        mine = torch.tensor([walker_steps / elapsed], dtype=torch.float64, device=reduce_device)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank_values = [float(v.item()) for v in everyone]
     # whole-job aggregate: sum of the ranks' work / slowest rank's time (tests/test_split_gloo.py covers this helper)
     _, elapsed, walker_steps, (accepted, gpu_ms, launches) = md.aggregate_throughput(
         elapsed, walker_steps, [float(accepted), gpu_ms, float(launches)], device=reduce_device)
@@ -461,6 +551,8 @@ def main():
                        "chain_memory": "none" if args.no_chain else ("pinned block from the library" if args.pinned_chain else "heap block (pageable)")},
             "roofline": roof,
         }
+        if per_rank_values is not None:
+            line["per_rank_values"] = per_rank_values
         if args.calc != "dense":
             line["config"]["workload"] += " [EXPERIMENT: calculator = %s, not the headline workload]" % args.calc
         if world == 1 and not args.no_secondary and args.calc == "dense":
@@ -484,6 +576,50 @@ def main():
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)
+    else:
+        line = None
+
+    if world > 1 and not args.no_split_leg and args.calc == "dense":
+        # Several ranks: the same ranks also step BASELINE config 5 -- ONE ensemble split between them, exchanged by the
+        # library -- for a bounded time, and the result rides along as a secondary measurement.  The headline above is
+        # complete at this point: a watchdog prints it without the split object and ends the process (exit, never
+        # re-exec) if the leg has not come back in time, e.g. with a rank stuck in a collective.
+        import threading
+        sampler.close()
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(args.split_leg_seconds):
+                return
+            if rank == 0:
+                line.setdefault("secondary", []).append({"workload": "C5 split over the ranks", "error": "did not finish within %.0f s; "
+                                                         "the headline above was complete before it started" % args.split_leg_seconds})
+                print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            loop = world if os.environ.get("MCMCPP_BENCH_SPLIT_LEG") == "loopback" else 0
+            if loop and rank != 0:
+                split = None  # (rehearsal: rank 0 alone steps all ranks as threads through the loop-back library)
+            else:
+                split = split_measurement(args, rank, local_rank, world, dist, torch, capi, steps=10, warmup=2, loopback_ranks=loop)
+            if loop and dist is not None:
+                dist.barrier()
+        except Exception as e:  # noqa: BLE001 -- the headline must not be lost to the secondary measurement
+            split = {"workload": "C5 split over the ranks", "error": "%s: %s" % (type(e).__name__, e)}
+        done.set()
+        if rank == 0 and split is not None:
+            split["workload"] = split.get("config", {}).get("workload", split.get("workload"))
+            line.setdefault("secondary", []).append(split)
+        if split is not None and "error" in split:
+            # (the other ranks may be stuck in a collective this rank never joined: their watchdogs end them; a tidy
+            #  shutdown of the process group would wait for them)
+            if rank == 0:
+                print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -97,8 +97,9 @@ typedef struct mcmcpp_hip_config {
      * communicator (created from comm_id, or taken from comm) and lets mcmcpp_hip_run step the split ensemble: the
      * handle's shard must be the rank's slice, [comm_rank * (W/2) / comm_world, + (W/2) / comm_world) -- shard_count = 0
      * selects exactly that -- and W/2 must divide by comm_world.  Every rank calls set_state / run / get_state with the
-     * same arguments; the exchanges (ncclAllGather of the updated rows, once per ensemble step) are enqueued on the
-     * launch stream by run itself, with no host round trip in between.  0 = no communicator. */
+     * same arguments; the exchanges (one ncclAllGather per ensemble step, see mcmcpp_hip_last_run_exchange) are enqueued on
+     * the launch stream by run itself.  If the preparation of a run fails on one rank, every rank's run returns an error
+     * and none has launched anything (the ranks agree on a status word first).  0 = no communicator. */
     int32_t comm_world;
     int32_t comm_rank;
     const void* comm_id;     /* MCMCPP_HIP_COMM_ID_BYTES bytes made by mcmcpp_hip_comm_unique_id on one rank and handed to
@@ -215,6 +216,17 @@ int mcmcpp_hip_last_run_timing(mcmcpp_hip_sampler* h, double* gpu_ms, int64_t* s
  * ensemble step's exchange, averaged over a sample of steps bracketed by HIP events (0 when none was sampled).
  * Any pointer may be NULL. */
 int mcmcpp_hip_last_run_host_timing(mcmcpp_hip_sampler* h, double* enqueue_ms, double* wall_ms, double* exchange_us_per_step);
+
+/* Split ensembles: what the exchanges of the last mcmcpp_hip_run moved.  Ranks of a communicator of more than one rank
+ * exchange only the rows that moved (index, log-posterior, row, packed into blocks of `block_slots` walkers per rank and
+ * all-gathered once per ensemble step -- once per half-step for slices too large for the one-launch-per-step kernels);
+ * the bound is learned from the run, and a chunk of steps in which some rank moved more walkers than a block holds is
+ * REPEATED from a snapshot with blocks that hold a whole slice, so the chain never depends on the bound.
+ *   bytes_per_step   bytes this rank received per ensemble step (all-gathering whole slices: (G-1)/G of the ensemble)
+ *   repeated_chunks  chunks of steps that were rolled back and repeated
+ *   block_slots      walkers per block at the end of the run (0: whole slices were all-gathered)
+ * Any pointer may be NULL. */
+int mcmcpp_hip_last_run_exchange(mcmcpp_hip_sampler* h, double* bytes_per_step, int64_t* repeated_chunks, int64_t* block_slots);
 
 /* ---- multi-GPU single ensemble (one handle per GPU) -------------------------------- */
 

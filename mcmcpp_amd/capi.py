@@ -19,7 +19,7 @@ EXPORTS = [
     "mcmcpp_hip_abi_version", "mcmcpp_hip_register_calculator", "mcmcpp_hip_create", "mcmcpp_hip_destroy", "mcmcpp_hip_last_error",
     "mcmcpp_hip_set_state", "mcmcpp_hip_seek", "mcmcpp_hip_run", "mcmcpp_hip_get_state", "mcmcpp_hip_reset_counters",
     "mcmcpp_hip_get_counters", "mcmcpp_hip_calc_logp", "mcmcpp_hip_last_run_timing", "mcmcpp_hip_last_run_host_timing",
-    "mcmcpp_hip_comm_unique_id", "mcmcpp_hip_run_async", "mcmcpp_hip_wait_stored", "mcmcpp_hip_run_wait",
+    "mcmcpp_hip_comm_unique_id", "mcmcpp_hip_last_run_exchange", "mcmcpp_hip_run_async", "mcmcpp_hip_wait_stored", "mcmcpp_hip_run_wait",
     "mcmcpp_hip_host_alloc", "mcmcpp_hip_host_free",
     "mcmcpp_hip_half_step_async", "mcmcpp_hip_bind_device_chain", "mcmcpp_hip_device_positions",
     "mcmcpp_hip_shard_span", "mcmcpp_hip_synchronize",
@@ -87,6 +87,7 @@ def lib():
         dp = C.POINTER(C.c_double)
         L.mcmcpp_hip_last_run_host_timing.argtypes = [vp, dp, dp, dp]
         L.mcmcpp_hip_comm_unique_id.argtypes = [vp]
+        L.mcmcpp_hip_last_run_exchange.argtypes = [vp, dp, C.POINTER(i64), C.POINTER(i64)]
         L.mcmcpp_hip_run_async.argtypes = [vp, i64, i32, vp, vp]
         L.mcmcpp_hip_wait_stored.argtypes = [vp, i64]
         L.mcmcpp_hip_run_wait.argtypes = [vp]
@@ -256,6 +257,12 @@ class HipSampler:
         v = [C.c_double(0) for _ in range(3)]
         self._check(lib().mcmcpp_hip_last_run_host_timing(self.h, *[C.byref(x) for x in v]))
         return v[0].value, v[1].value, v[2].value
+
+    def last_run_exchange(self):
+        """Split ensembles: (bytes this rank received per ensemble step, chunks repeated with larger blocks, slots per block)"""
+        b, r, c = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        self._check(lib().mcmcpp_hip_last_run_exchange(self.h, C.byref(b), C.byref(r), C.byref(c)))
+        return b.value, r.value, c.value
 
     def half_step_async(self, color, save_slot=-1):
         self._check(lib().mcmcpp_hip_half_step_async(self.h, color, save_slot))

@@ -26,6 +26,7 @@
 #include "../../include/mcmcpp_hip.h"
 #define MCMCPP_DEFINE_REDUCE_KERNEL
 #include "launch_table.hpp"
+#include "exchange_kernels.hpp"
 #include "rccl_dyn.hpp"
 #include "sampler_base.hpp"
 
@@ -94,6 +95,10 @@ struct Knobs
     long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
+    long comm_compact;            // MCMCPP_HIP_COMM_COMPACT             split ensembles of more than one rank: 1 = exchange only the rows that moved (1), 0 = all-gather the slices
+    long comm_compact_cap;        // MCMCPP_HIP_COMM_COMPACT_CAP         slots of an exchange block (0: learned from the run; a bound that is too small costs
+                                  //                                     a repeated chunk, never a wrong chain)
+    long comm_compact_chunk;      // MCMCPP_HIP_COMM_COMPACT_CHUNK       ensemble steps between two looks at the overflow flag (256)
     long force_multi_chain_kernels; // MCMCPP_HIP_FORCE_MC                experiments: single ensembles stepped by the several-chains instantiations (0)
     static Knobs from_environment()
     {
@@ -115,6 +120,10 @@ struct Knobs
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
         k.force_multi_chain_kernels = env_long("MCMCPP_HIP_FORCE_MC", 0);
+        k.comm_compact = env_long("MCMCPP_HIP_COMM_COMPACT", 1);
+        k.comm_compact_cap = env_long("MCMCPP_HIP_COMM_COMPACT_CAP", 0);
+        k.comm_compact_chunk = env_long("MCMCPP_HIP_COMM_COMPACT_CHUNK", 256);
+        if (k.comm_compact_chunk < 1) k.comm_compact_chunk = 1;
         return k;
     }
 };
@@ -350,6 +359,19 @@ public:
             }
         }
 
+        if (c.comm_world > 1 && knobs.comm_compact != 0)
+        {
+            const uint32_t cap_full = (uint32_t)((full_fn ? 2 : 1) * shard_count);
+            void* p = nullptr;
+            HIP_TRY(hipMalloc(&p, xblock_bytes<T>(cap_full, D) * (size_t)c.comm_world));
+            d_xblocks = (char*)p;
+            HIP_TRY(hipMalloc(&p, sizeof(uint32_t) * (size_t)W));
+            d_seen = (uint32_t*)p;
+            HIP_TRY(hipMalloc(&p, sizeof(XStats)));
+            d_xstats = (XStats*)p;
+            HIP_TRY(hipMalloc(&p, sizeof(T) * (size_t)W * D + (sizeof(T) + sizeof(uint32_t)) * (size_t)W + sizeof(Diag)));
+            d_snap = (char*)p;
+        }
         if (K > 1 && (!whole || c.comm_world >= 1 || c.device_positions))
             return fail(MCMCPP_HIP_E_ARG, "num_chains > 1: whole ensembles on one device only (no shards, communicator or caller-owned positions)");
         if (c.flags & MCMCPP_HIP_FLAG_CALLER_STREAM)
@@ -892,11 +914,52 @@ public:
 
     static constexpr int kMaxExchangeSamples = 32;
 
+    // ---- the exchange of moved rows only (exchange_kernels.hpp) ----------------------------------------------------------
+    // pack -> one all-gather of G equal blocks of `cap` slots -> scatter into the replica (both position buffers when
+    // `other_pos` is given).  Colours [color0, color0 + colors) of this rank's slice.
+    int exchange_compact(T* cur_pos, T* other_pos, T* cur_logp, T* other_logp, int color0, int colors, uint32_t cap)
+    {
+        const size_t bb = xblock_bytes<T>(cap, D);
+        char* own = d_xblocks + bb * (size_t)cfg.comm_rank;
+        const int lanes = colors * shard_count;
+        hipLaunchKernelGGL(exchange_pack_kernel<T>, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, (const T*)cur_pos, (const T*)cur_logp,
+                           (const uint32_t*)d_nacc, d_seen, own, cap, n, D, shard_begin, shard_count, color0, colors);
+        HIP_TRY(hipGetLastError());
+        NCCL_TRY(rccl->AllGather(own, d_xblocks, bb, ncclInt8, comm, stream));
+        const bool vec = ((size_t)D * sizeof(T)) % 16 == 0;
+        const int pieces = vec ? (int)((size_t)D * sizeof(T) / 16) : D;
+        int lpr = 1;
+        while (lpr < pieces && lpr < 64) lpr <<= 1;
+        const unsigned rows_per_block = 256u / (unsigned)lpr;
+        hipLaunchKernelGGL(exchange_scatter_kernel<T>, dim3((cap + rows_per_block - 1) / rows_per_block, (unsigned)(cfg.comm_world - 1)), dim3(256), 0, stream,
+                           d_xblocks, bb, cap, cfg.comm_world, cfg.comm_rank, D, cur_pos, other_pos, cur_logp, other_logp, d_xstats);
+        HIP_TRY(hipGetLastError());
+        return MCMCPP_HIP_OK;
+    }
+
+    // (seen counters of the own slice <- accepted counters; statistics and the own block's count <- 0)
+    int exchange_reset(uint32_t cap)
+    {
+        hipLaunchKernelGGL(exchange_sync_seen_kernel, dim3((unsigned)((2 * shard_count + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)d_nacc, d_seen, n,
+                           shard_begin, shard_count);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(d_xstats, 0, sizeof(XStats), stream));
+        HIP_TRY(hipMemsetAsync(d_xblocks + xblock_bytes<T>(cap, D) * (size_t)cfg.comm_rank, 0, sizeof(XBlockHeader), stream));
+        return MCMCPP_HIP_OK;
+    }
+
+    // One ensemble over the ranks of a communicator.  The run proceeds in CHUNKS of steps; the host waits for the device
+    // only at the end of a chunk, and only when it has a reason to: stored steps to hand out (a staging buffer's worth), or
+    // -- exchanging moved rows only -- the overflow flag to look at.  A chunk whose blocks overflowed is rolled back to the
+    // snapshot taken in front of it and repeated with blocks that hold a whole slice; the slot bound of the following
+    // chunks is what the last one needed, plus an eighth.
     int run_split(int64_t n_saved, int32_t interval, void* chain_out, uint32_t* accepted_per_step)
     {
         last_ms = 0.0;
         last_launches = 0;
         host_enqueue_ms = host_wall_ms = exchange_us_per_step = 0.0;
+        xchg_bytes_per_step = 0.0;
+        xchg_rollbacks = 0;
         const auto tp0 = std::chrono::steady_clock::now();
         int64_t stage_slots = 0;
         const int prep = prepare_split(n_saved, interval, chain_out, accepted_per_step, &stage_slots);
@@ -929,83 +992,185 @@ public:
             hipLaunchKernelGGL(mark_rows_moved_kernel, dim3((unsigned)((W + 255) / 256)), dim3(256), 0, stream, d_nacc, W, kRowMovedBit);
             HIP_TRY(hipGetLastError());
         }
-        enq_step = half_steps >> 1;
+        const uint64_t half_steps0 = half_steps;  // (the member moves on when the run has succeeded)
+        enq_step = half_steps0 >> 1;
         run_step = 0;
         args_red = make_args(0);
         args_blk = make_args(1);
         // engine state in front of the red half-step of the coming ensemble step (what write_ctl put into the control record)
-        U128 red_base = apply(pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps), state0);
+        U128 red_base = apply(pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps0), state0);
         HalfStepArgs<T> fill_red = make_args(0);
         fill_red.shard_begin = 0;
         fill_red.shard_count = n;
 
-        const int64_t sample_stride = total > kMaxSamples ? total / kMaxSamples : 1;
-        int samples = 0, unreduced = 0;
-        int64_t staged = 0, handed = 0;  // stored steps copied to staging / handed to the caller
-        auto drain_stage = [&]() -> int {
-            HIP_TRY(hipStreamSynchronize(stream));
-            std::memcpy((char*)chain_out + step_bytes * (size_t)handed, h_split_stage, step_bytes * (size_t)(staged - handed));
-            handed = staged;
-            publish_stored(handed);
-            return MCMCPP_HIP_OK;
-        };
-        HIP_TRY(hipEventRecord(ev_t0[0], stream));
-        const auto tp1 = std::chrono::steady_clock::now();
-        for (int64_t s = 0; s < total; ++s)
+        const bool compact = d_xblocks != nullptr;
+        const uint32_t cap_full = (uint32_t)((full_fn ? 2 : 1) * shard_count);  // a block that holds every walker of an exchange
+        uint32_t cap = cap_full;
+        if (compact)
         {
-            const int parity = (int)(enq_step & 1), pos_parity = (int)(run_step & 1);
-            const bool sample = samples < kMaxSamples && s % sample_stride == 0;
-            T* cur_pos = d_pos;  // the replica that holds the ensemble after this step
+            if (knobs.comm_compact_cap > 0)
+                cap = (uint32_t)(knobs.comm_compact_cap < (long)cap_full ? knobs.comm_compact_cap : (long)cap_full);
+            else if (xcap_learned > 0)
+                cap = xcap_learned < cap_full ? xcap_learned : cap_full;
             if (full_fn)
             {
-                fill_red.draw_parity = parity;
-                launch_fill_draws(fill_red, red_base, nullptr, stream);
-                enqueue_step(parity, pos_parity);
-                // (the per-wavefront accepted counts are summed once per partial_slots steps, and at the end of the run)
-                if (++unreduced == partial_slots || s + 1 == total)
+                // a remote walker's row must be current in BOTH buffers (the scatter keeps it so from here on)
+                HIP_TRY(hipMemcpyAsync(d_pos_alt, d_pos, step_bytes, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_logp + W, d_logp, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+            }
+        }
+
+        const int64_t sample_stride = total > kMaxSamples ? total / kMaxSamples : 1;
+        int samples = 0;
+        int64_t handed = 0;  // stored steps handed to the caller
+        double xbytes = 0.0;  // bytes this rank received in the exchanges of the steps that count
+        bool learning = compact && knobs.comm_compact_cap <= 0 && xcap_learned == 0;  // first chunk: short, whole-slice blocks
+        HIP_TRY(hipEventRecord(ev_t0[0], stream));
+        const auto tp1 = std::chrono::steady_clock::now();
+        int64_t s0 = 0;  // first step of the chunk in hand
+        while (s0 < total)
+        {
+            // ---- how far this chunk goes
+            int64_t len = total - s0;
+            if (compact)
+            {
+                const int64_t want = learning ? 16 : knobs.comm_compact_chunk;
+                if (len > want) len = want;
+            }
+            if (chain_out)
+            {
+                const int64_t fits = (s0 / interval + stage_slots) * (int64_t)interval - s0;  // steps until the staging buffer is full
+                if (len > fits) len = fits;
+            }
+            if (compact)
+            {
+                // snapshot: everything a repeated chunk must find as this one found it
+                T* cur = (full_fn && (run_step & 1)) ? d_pos_alt : d_pos;
+                T* curl = (full_fn && (run_step & 1)) ? d_logp + W : d_logp;
+                HIP_TRY(hipMemcpyAsync(d_snap, cur, step_bytes, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_snap + step_bytes, curl, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_snap + step_bytes + sizeof(T) * (size_t)W, d_nacc, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(d_snap + step_bytes + (sizeof(T) + sizeof(uint32_t)) * (size_t)W, d_diag, sizeof(Diag), hipMemcpyDeviceToDevice, stream));
+                if ((rc = exchange_reset(cap))) return rc;
+            }
+            int unreduced = 0;
+            int64_t staged = handed;
+            const int samples_before = samples;
+            for (int64_t s = s0; s < s0 + len; ++s)
+            {
+                const int parity = (int)(enq_step & 1), pos_parity = (int)(run_step & 1);
+                const bool sample = samples < kMaxSamples && s % sample_stride == 0;
+                const bool last_of_chunk = s + 1 == s0 + len;
+                T* cur_pos = d_pos;  // the replica that holds the ensemble after this step
+                if (full_fn)
                 {
-                    launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
-                    unreduced = 0;
+                    fill_red.draw_parity = parity;
+                    launch_fill_draws(fill_red, red_base, nullptr, stream);
+                    enqueue_step(parity, pos_parity);
+                    // (the per-wavefront accepted counts are summed once per partial_slots steps, and at the end of a chunk)
+                    if (++unreduced == partial_slots || last_of_chunk)
+                    {
+                        launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                        unreduced = 0;
+                    }
+                    HIP_TRY(hipGetLastError());
+                    cur_pos = pos_parity ? d_pos : d_pos_alt;
+                    T* other_pos = pos_parity ? d_pos_alt : d_pos;
+                    T* cur_logp = pos_parity ? d_logp : d_logp + W;
+                    T* other_logp = pos_parity ? d_logp + W : d_logp;
+                    if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
+                    rc = compact ? exchange_compact(cur_pos, other_pos, cur_logp, other_logp, 0, 2, cap) : exchange_rows(cur_pos, cur_logp, 0, 2);
+                    if (rc) return rc;
+                    if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
+                    red_base = apply(half_jump, apply(half_jump, red_base));
                 }
-                HIP_TRY(hipGetLastError());
-                cur_pos = pos_parity ? d_pos : d_pos_alt;
-                T* cur_logp = pos_parity ? d_logp : d_logp + W;
-                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
-                rc = exchange_rows(cur_pos, cur_logp, 0, 2);
-                if (rc) return rc;
-                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
-                red_base = apply(half_jump, apply(half_jump, red_base));
+                else
+                {
+                    args_red.draw_parity = parity;
+                    args_blk.draw_parity = parity;
+                    half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
+                    HIP_TRY(hipGetLastError());
+                    if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
+                    rc = compact ? exchange_compact(d_pos, nullptr, d_logp, nullptr, 0, 1, cap) : exchange_rows(d_pos, nullptr, 0, 1);
+                    if (rc) return rc;
+                    if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
+                    half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
+                    if (++unreduced == partial_slots || last_of_chunk)
+                    {
+                        launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
+                        unreduced = 0;
+                    }
+                    HIP_TRY(hipGetLastError());
+                    rc = compact ? exchange_compact(d_pos, nullptr, d_logp, nullptr, 1, 1, cap) : exchange_rows(d_pos, nullptr, 1, 1);
+                    if (rc) return rc;
+                }
+                if (sample) ++samples;
+                enq_step += 1;
+                run_step += 1;
+                if (chain_out && (s + 1) % interval == 0)
+                {
+                    HIP_TRY(hipMemcpyAsync((char*)h_split_stage + step_bytes * (size_t)(staged - handed), cur_pos, step_bytes, hipMemcpyDeviceToHost, stream));
+                    ++staged;
+                }
+            }
+            // ---- end of the chunk
+            const bool more = s0 + len < total;
+            if (compact)
+            {
+                XStats* hx = reinterpret_cast<XStats*>((char*)h_pinned + 96);
+                HIP_TRY(hipMemcpyAsync(hx, d_xstats, sizeof(XStats), hipMemcpyDeviceToHost, stream));
+                HIP_TRY(hipStreamSynchronize(stream));
+                if (hx->overflow)
+                {
+                    // Some block of some exchange of this chunk was too small: whatever the chunk computed rests on a
+                    // replica that missed rows.  Back to the snapshot -- into both buffers, so that the repeated chunk may
+                    // start at buffer 0 like a run does -- and once more with blocks nothing can overflow.  Every rank
+                    // reads the same gathered headers, so every rank takes this branch together.
+                    ++xchg_rollbacks;
+                    HIP_TRY(hipMemcpyAsync(d_pos, d_snap, step_bytes, hipMemcpyDeviceToDevice, stream));
+                    HIP_TRY(hipMemcpyAsync(d_logp, d_snap + step_bytes, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                    if (full_fn)
+                    {
+                        HIP_TRY(hipMemcpyAsync(d_pos_alt, d_snap, step_bytes, hipMemcpyDeviceToDevice, stream));
+                        HIP_TRY(hipMemcpyAsync(d_logp + W, d_snap + step_bytes, sizeof(T) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                    }
+                    HIP_TRY(hipMemcpyAsync(d_nacc, d_snap + step_bytes + sizeof(T) * (size_t)W, sizeof(uint32_t) * (size_t)W, hipMemcpyDeviceToDevice, stream));
+                    HIP_TRY(hipMemcpyAsync(d_diag, d_snap + step_bytes + (sizeof(T) + sizeof(uint32_t)) * (size_t)W, sizeof(Diag), hipMemcpyDeviceToDevice, stream));
+                    half_steps = half_steps0 + 2 * (uint64_t)s0;
+                    records_valid = false;
+                    rc = write_ctl((uint64_t)s0, interval);
+                    half_steps = half_steps0;
+                    if (rc) return rc;
+                    enq_step = (half_steps0 >> 1) + (uint64_t)s0;
+                    run_step = 0;
+                    red_base = apply(pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * ((unsigned __int128)half_steps0 + 2 * (unsigned __int128)s0)), state0);
+                    samples = samples_before;
+                    cap = cap_full;
+                    continue;  // (the same chunk again)
+                }
+                xbytes += (double)len * (double)(full_fn ? 1 : 2) * (double)(cfg.comm_world - 1) * (double)xblock_bytes<T>(cap, D);
+                if (knobs.comm_compact_cap <= 0)
+                {
+                    // the next chunk's bound: what this one needed, plus an eighth and a little
+                    uint64_t want = (uint64_t)hx->max_count + hx->max_count / 8 + 64;
+                    want = (want + 63) & ~(uint64_t)63;
+                    cap = want < cap_full ? (uint32_t)want : cap_full;
+                    xcap_learned = cap;
+                }
+                else
+                    cap = (uint32_t)(knobs.comm_compact_cap < (long)cap_full ? knobs.comm_compact_cap : (long)cap_full);
+                learning = false;
             }
             else
+                xbytes += (double)len * (double)(cfg.comm_world - 1) * (double)shard_count * 2.0 * (double)((size_t)D + (full_fn ? 1 : 0)) * sizeof(T);
+            if (chain_out && staged > handed && (staged - handed == stage_slots || !more || compact))
             {
-                args_red.draw_parity = parity;
-                args_blk.draw_parity = parity;
-                half_fn(args_red, grid_blocks_for(args_red.shard_count), stream);
-                HIP_TRY(hipGetLastError());
-                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples], stream));
-                rc = exchange_rows(d_pos, nullptr, 0, 1);
-                if (rc) return rc;
-                if (sample) HIP_TRY(hipEventRecord(ev_x[2 * samples + 1], stream));
-                half_fn(args_blk, grid_blocks_for(args_blk.shard_count), stream);
-                if (++unreduced == partial_slots || s + 1 == total)
-                {
-                    launch_accepted_reduce(d_partials, partial_slots, partial_waves, unreduced, ctl_after((int64_t)run_step + 1), d_run, stream, K);
-                    unreduced = 0;
-                }
-                HIP_TRY(hipGetLastError());
-                rc = exchange_rows(d_pos, nullptr, 1, 1);
-                if (rc) return rc;
+                HIP_TRY(hipStreamSynchronize(stream));
+                std::memcpy((char*)chain_out + step_bytes * (size_t)handed, h_split_stage, step_bytes * (size_t)(staged - handed));
+                handed = staged;
+                publish_stored(handed);
             }
-            if (sample) ++samples;
-            enq_step += 1;
-            run_step += 1;
-            if (chain_out && (s + 1) % interval == 0)
-            {
-                HIP_TRY(hipMemcpyAsync((char*)h_split_stage + step_bytes * (size_t)(staged - handed), cur_pos, step_bytes, hipMemcpyDeviceToHost, stream));
-                ++staged;
-                if (staged - handed == stage_slots && s + 1 < total)
-                    if ((rc = drain_stage())) return rc;
-            }
+            s0 += len;
         }
         const auto tp2 = std::chrono::steady_clock::now();
         if (full_fn && (run_step & 1))
@@ -1020,13 +1185,12 @@ public:
         NCCL_TRY(rccl->GroupStart());
         for (int c = 0; c < 2; ++c)
         {
-            if (!full_fn)
+            if (!full_fn && !compact)  // (the exchanges of the other schemes carry the log-posteriors along)
                 NCCL_TRY(rccl->AllGather(d_logp + (size_t)c * n + shard_begin, d_logp + (size_t)c * n, (size_t)shard_count, RcclType<T>::value, comm, stream));
             NCCL_TRY(rccl->AllGather(d_nacc + (size_t)c * n + shard_begin, d_nacc + (size_t)c * n, (size_t)shard_count, ncclUint32, comm, stream));
         }
         if (accepted_per_step) NCCL_TRY(rccl->AllReduce(d_acc, d_acc, (size_t)total, ncclUint32, ncclSum, comm, stream));
         NCCL_TRY(rccl->GroupEnd());
-        if (chain_out && (rc = drain_stage())) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
         {
             float ms = 0.f;
@@ -1041,6 +1205,8 @@ public:
             // (half-step scheme: the sampled exchange is the red one, the black one moves as much)
             exchange_us_per_step = samples ? sum / samples * 1e3 * (full_fn ? 1.0 : 2.0) : 0.0;
         }
+        xchg_bytes_per_step = xbytes / (double)total;
+        xchg_cap_slots = compact ? (int64_t)cap : 0;
         last_launches = full_fn ? total : 2 * total;
         half_steps += 2 * (uint64_t)total;
         steps_since_reset += (uint64_t)total;
@@ -1442,7 +1608,8 @@ private:
     }
 
     // device StepCtl[0] <- {stream position of half-step `half_steps`, counters}; half_steps must be even
-    int write_ctl(uint64_t step_in_run)
+    // step_in_run > 0 (a chunk of a split run being repeated): the counters the kernels keep instead of dividing follow
+    int write_ctl(uint64_t step_in_run, int32_t interval = 1)
     {
         const Affine128 j = pcg_jump(inc, (unsigned __int128)3 * (unsigned)n * (unsigned __int128)half_steps);
         // the draw records of the next red and the next black half-step (afterwards the launches keep them going):
@@ -1456,9 +1623,9 @@ private:
             c->state2 = apply(half_jump, state1);
             c->half_step = half_steps;
             c->step_in_run = step_in_run;
-            c->chain_slot = 0;
-            c->save_phase = 0;
-            c->partial_slot = 0;
+            c->chain_slot = (long long)(step_in_run / (uint64_t)interval);
+            c->save_phase = (uint32_t)(step_in_run % (uint64_t)interval);
+            c->partial_slot = (uint32_t)(step_in_run % (uint64_t)partial_slots);
             HIP_TRY(hipMemcpyAsync(ctl_of(k) + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
             if (refill)
             {
@@ -1702,6 +1869,10 @@ private:
             hipStreamSynchronize(copy_stream);
             hipStreamDestroy(copy_stream);
         }
+        if (d_xblocks) hipFree(d_xblocks);
+        if (d_seen) hipFree(d_seen);
+        if (d_xstats) hipFree(d_xstats);
+        if (d_snap) hipFree(d_snap);
         if (own_comm && comm && rccl) (void)rccl->CommDestroy(comm);
         if (h_split_stage) hipHostFree(h_split_stage);
         for (hipEvent_t e : ev_x)
@@ -1714,6 +1885,12 @@ private:
     const Rccl* rccl = nullptr;  // split ensembles only
     ncclComm_t comm = nullptr;
     bool own_comm = false;
+    // split ensembles of more than one rank, exchanging moved rows only (exchange_kernels.hpp)
+    char* d_xblocks = nullptr;      // [comm_world][block]: this rank's block and, behind the all-gather, everybody's
+    uint32_t* d_seen = nullptr;     // [W]: a walker's accepted counter as of the last exchange (own slice)
+    XStats* d_xstats = nullptr;
+    char* d_snap = nullptr;         // positions, log-posteriors, counters, diagnostics in front of the chunk in hand
+    uint32_t xcap_learned = 0;      // the slot bound the last run ended with
     void* h_split_stage = nullptr;  // split ensembles: pinned staging of stored steps
     size_t split_stage_capacity = 0;
     std::vector<hipEvent_t> ev_x;   // split ensembles: events around a sample of exchanges
@@ -2047,6 +2224,14 @@ int mcmcpp_hip_last_run_host_timing(mcmcpp_hip_sampler* h, double* enqueue_ms, d
     if (enqueue_ms) *enqueue_ms = h->host_enqueue_ms;
     if (wall_ms) *wall_ms = h->host_wall_ms;
     if (exchange_us_per_step) *exchange_us_per_step = h->exchange_us_per_step;
+    return MCMCPP_HIP_OK;
+}
+int mcmcpp_hip_last_run_exchange(mcmcpp_hip_sampler* h, double* bytes_per_step, int64_t* repeated_chunks, int64_t* block_slots)
+{
+    NEED_H;
+    if (bytes_per_step) *bytes_per_step = h->xchg_bytes_per_step;
+    if (repeated_chunks) *repeated_chunks = h->xchg_rollbacks;
+    if (block_slots) *block_slots = h->xchg_cap_slots;
     return MCMCPP_HIP_OK;
 }
 int mcmcpp_hip_comm_unique_id(void* id_out)

@@ -19,6 +19,10 @@ struct mcmcpp_hip_sampler
     std::string error;
     // host-side cost of the last run (mcmcpp_hip_last_run_host_timing)
     double host_enqueue_ms = 0.0, host_wall_ms = 0.0, exchange_us_per_step = 0.0;
+    // split ensembles (mcmcpp_hip_last_run_exchange): bytes this rank received per ensemble step of the last run, chunks of
+    // steps that had to be repeated with larger exchange blocks, slots of a block at the end of the run
+    double xchg_bytes_per_step = 0.0;
+    int64_t xchg_rollbacks = 0, xchg_cap_slots = 0;
     // mcmcpp_hip_run_async: the run executes on a worker thread owned by the handle; stored steps are announced as they
     // reach the caller's memory
     std::thread async_worker;

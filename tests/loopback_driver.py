@@ -32,8 +32,10 @@ def _params(calc, D, rng):
 
 
 def run_ranks(G, W, D, calc, dtype=capi.F64, scheme="step", runs=((3, 2), (1, 1), (2, 3)), chain_on="all", seed=9, env=None,
-              oracle_threads=4, bad_rank=None):
-    """One ensemble over G ranks; returns a list of problems (empty: everything equal to the oracle)."""
+              oracle_threads=4, bad_rank=None, expect=None):
+    """One ensemble over G ranks; returns a list of problems (empty: everything equal to the oracle).
+    expect: optional check of the exchange statistics, called with [(bytes per step, repeated chunks, block slots)] of
+    rank 0's runs; returns a list of problems."""
     env = dict(env or {})
     env["MCMCPP_HIP_COMM_FULL_STEP"] = "1" if scheme == "step" else "0"
     saved_env = {k: os.environ.get(k) for k in env}
@@ -71,7 +73,7 @@ def run_ranks(G, W, D, calc, dtype=capi.F64, scheme="step", runs=((3, 2), (1, 1)
                 for n_saved, interval in runs:
                     keep = chain_on == "all" or r == 0
                     chain, acc = hip.run(n_saved, interval=interval, save_chain=keep)
-                    out.append((chain, acc, hip.get_state()))
+                    out.append((chain, acc, hip.get_state(), hip.last_run_exchange()))
                 out.append(hip.counters())
                 out.append(hip.last_run_host_timing())
                 got[r] = out
@@ -94,7 +96,7 @@ def run_ranks(G, W, D, calc, dtype=capi.F64, scheme="step", runs=((3, 2), (1, 1)
                 if not verdict.startswith("error"):
                     problems.append("rank %d: the bad request of rank %d went unnoticed (%s)" % (r, bad_rank, verdict))
             for k, (n_saved, interval) in enumerate(runs):
-                chain, acc, state = out[k]
+                chain, acc, state, xstats = out[k]
                 wchain, wacc, wstate = want[k]
                 if not np.array_equal(acc, wacc):
                     problems.append("rank %d run %d: accepted counts differ" % (r, k))
@@ -108,6 +110,13 @@ def run_ranks(G, W, D, calc, dtype=capi.F64, scheme="step", runs=((3, 2), (1, 1)
                 problems.append("rank %d: near ties %d, redraws %d" % (r, c["near_ties"], c["redraws"]))
             if c["ensemble_steps"] != sum(a * b for a, b in runs):
                 problems.append("rank %d: %d ensemble steps counted" % (r, c["ensemble_steps"]))
+        if not problems:
+            # every rank took the same decisions about its exchange blocks
+            for k in range(len(runs)):
+                if len({got[r][k][3][1:] for r in range(G)}) != 1:
+                    problems.append("run %d: the ranks disagree about repeated chunks / block slots: %r" % (k, [got[r][k][3] for r in range(G)]))
+            if expect is not None:
+                problems += expect([got[0][k][3] for k in range(len(runs))])
         # the ranks' own accepted totals add up to the ensemble's
         if not problems:
             total = sum(got[r][len(runs)]["accepted"] for r in range(G))
@@ -140,6 +149,44 @@ for _scheme in ("step", "half"):
     case("rosen1024x7_G8_%s" % _scheme)(lambda scheme=_scheme: run_ranks(8, 1024, 7, po.CALC_ROSENBROCK, scheme=scheme))
     case("iso2048x16_f32_G2_%s" % _scheme)(lambda scheme=_scheme: run_ranks(2, 2048, 16, po.CALC_ISO_GAUSSIAN, dtype=capi.F32, scheme=scheme))
     case("iso6144x24_G3_%s" % _scheme)(lambda scheme=_scheme: run_ranks(3, 6144, 24, po.CALC_ISO_GAUSSIAN, scheme=scheme, runs=((4, 1), (3, 3))))
+# whole slices all-gathered (MCMCPP_HIP_COMM_COMPACT=0): what a communicator of more than one rank did before it learned
+# to send moved rows only
+for _scheme in ("step", "half"):
+    case("iso8192x64_G4_%s_whole_slices" % _scheme)(lambda scheme=_scheme: run_ranks(
+        4, 8192, 64, po.CALC_ISO_GAUSSIAN, scheme=scheme, env={"MCMCPP_HIP_COMM_COMPACT": "0"},
+        expect=lambda st: [] if all(x[2] == 0 and x[1] == 0 and x[0] > 0 for x in st) else ["statistics %r" % (st,)]))
+
+
+def _expect_repeats(st):
+    return [] if all(x[1] >= 1 for x in st) else ["no chunk was repeated although the blocks were too small: %r" % (st,)]
+
+
+def _expect_learned(full_slots, full_bytes):
+    def check(st):
+        last = st[-1]
+        bad = []
+        if not (0 < last[2] < full_slots // 2):
+            bad.append("the slot bound was not learned: %r (a whole slice: %d)" % (st, full_slots))
+        if not (0 < last[0] < full_bytes / 2):
+            bad.append("bytes per step %r against %d for whole slices" % (st, full_bytes))
+        return bad
+    return check
+
+
+# blocks that are too small on purpose (8 slots; chunks of 3 steps): every chunk overflows, is rolled back and repeated --
+# with stored steps handed out only from chunks that held, an odd number of steps per run, both schemes
+for _scheme in ("step", "half"):
+    case("forced_overflow_G2_%s" % _scheme)(lambda scheme=_scheme: run_ranks(
+        2, 4096, 32, po.CALC_DENSE_GAUSSIAN, scheme=scheme, runs=((5, 1), (3, 3), (1, 1)), env={"MCMCPP_HIP_COMM_COMPACT_CAP": "8", "MCMCPP_HIP_COMM_COMPACT_CHUNK": "3"},
+        expect=_expect_repeats))
+    case("forced_overflow_G8_%s" % _scheme)(lambda scheme=_scheme: run_ranks(
+        8, 8192, 64, po.CALC_ISO_GAUSSIAN, scheme=scheme, runs=((7, 2),), chain_on="rank0", env={"MCMCPP_HIP_COMM_COMPACT_CAP": "8", "MCMCPP_HIP_COMM_COMPACT_CHUNK": "4"},
+        expect=_expect_repeats))
+    # the bound learned from the run: 16 steps with whole-slice blocks, then what the chunk needed plus an eighth; chunks
+    # of 7 steps so that stored steps (every third) fall on both sides of chunk ends
+    case("learned_bound_G4_%s" % _scheme)(lambda scheme=_scheme: run_ranks(
+        4, 8192, 64, po.CALC_ISO_GAUSSIAN, scheme=scheme, runs=((14, 3), (5, 2)), env={"MCMCPP_HIP_COMM_COMPACT_CHUNK": "7"},
+        expect=_expect_learned((2 if scheme == "step" else 1) * 1024, 3 * 2048 * 65 * 8)))
 case("one_rank_fails_before_the_first_launch")(lambda: run_ranks(4, 4096, 32, po.CALC_ISO_GAUSSIAN, runs=((2, 2),), bad_rank=2))
 # BASELINE config 5 at full size, eight ranks (8 192 walkers of each colour per rank): one exchange per ensemble step, then
 # the reference's scheme (one per half-step)
