@@ -163,27 +163,40 @@ def counter_traffic(kernel, secondary_key=None):
     return None, None
 
 
-def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0, rows_read=2):
-    """(2D+1)*8 read + (D+1)*8 written per walker update (+ D*8 when the step is stored), fp64, times the
-    walker updates one launch performs, over the average launch duration (HIP events on the launch stream).
-    rows_read = 3: Mover::DifferentialEvolution, whose update reads two partner rows."""
-    bytes_per_update = (rows_read * D + 1) * 8 + (D + 1) * 8
+def residency_note(W, D, elem, chains=1, buffers=1):
+    """Where the walkers live between two launches: ensembles below the 256 MiB of Infinity Cache never reach HBM, so their
+    roofline fraction (algorithmic bytes over the HBM peak) is a NOMINAL figure -- it can exceed what HBM itself delivers
+    (about 6.3 of the 8 TB/s, MI355X_MICROARCH.md) and says how far the launch is from the bandwidth bound, not from HBM."""
+    mib = W * D * elem * chains * buffers / 2.0**20
+    if mib < 256:
+        return "positions %.0f MiB: resident in Infinity Cache (256 MiB); the fraction of the 8 TB/s HBM peak is nominal" % mib
+    return "positions %.0f MiB: beyond Infinity Cache, served by HBM" % mib
+
+
+def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0, rows_read=2, elem=8, chains=1):
+    """(2D+1)*s read + (D+1)*s written per walker update (+ D*s when the step is stored), s = element size
+    (8: fp64, 4: fp32), times the walker updates one launch performs, over the average launch duration (HIP events on the
+    launch stream).  rows_read = 3: Mover::DifferentialEvolution, whose update reads two partner rows."""
+    bytes_per_update = (rows_read * D + 1) * elem + (D + 1) * elem
     updates_per_launch = walker_steps / launches
-    bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * 8)
+    bytes_per_launch = updates_per_launch * (bytes_per_update + saved_fraction * D * elem)
     us_per_launch = gpu_ms * 1e3 / launches
     achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    full_step = updates_per_launch > 0.75 * W * chains
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "kernel": kernel, "walker_updates_per_launch": updates_per_launch,
-            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch}
+            "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us_per_launch,
+            "residency": residency_note(W, D, elem, chains, 2 if full_step else 1)}
 
 
-def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1, mover=None, traffic_key=None):
+def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, batch, seconds=1.0, chains=1, mover=None, traffic_key=None, dtype=0):
     """One of the other single-GPU configurations: runs of `batch` ensemble steps (nothing stored) for about `seconds`,
-    with its roofline.  chains > 1: that many independent ensembles (seeds 0, 1, ...) stepped by the same launches."""
+    with its roofline.  chains > 1: that many independent ensembles (seeds 0, 1, ...) stepped by the same launches.
+    dtype: capi.F64 (0) / capi.F32 (1), the ParamType of the reference's templates."""
     if mover is None:
-        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, num_chains=chains)
+        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, num_chains=chains, dtype=dtype)
     else:
-        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, mover=mover)
+        s = capi.HipSampler(W, D, calc, params, seed=0, device=device, mover=mover, dtype=dtype)
     pos = np.stack([workloads.init_positions(W, D, salt=k) for k in range(chains)]) if chains > 1 else workloads.init_positions(W, D, salt=0)
     s.set_state(pos, s.calc_logp(pos))
     s.run(1, interval=batch, save_chain=False)
@@ -200,10 +213,10 @@ def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, 
     dt = time.perf_counter() - t0
     ws = float(W) * chains * batch * reps
     s.close()
-    roof = roofline_of(W, D, ws, launches, gpu_ms, kernel, rows_read=3 if mover is not None else 2)
+    roof = roofline_of(W, D, ws, launches, gpu_ms, kernel, rows_read=3 if mover is not None else 2, elem=4 if dtype == 1 else 8, chains=chains)
     if traffic_key is not None:
         roof["traffic"], roof["traffic_source"] = counter_traffic(kernel, traffic_key)
-    return {"workload": name, "walkers": W, "dims": D, "chains": chains, "value": ws / dt, "unit": "walker-steps/s",
+    return {"workload": name, "walkers": W, "dims": D, "chains": chains, "dtype": "f32" if dtype == 1 else "f64", "value": ws / dt, "unit": "walker-steps/s",
             "ensemble_steps": batch * reps, "seconds": dt, "acceptance_rate": accepted / ws, "roofline": roof}
 
 
@@ -526,7 +539,8 @@ def main():
         roof["traffic_source"] = (traffic_file + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE doubled per "
                                   "the gfx950 correction; taken from the sources this library was built from)") if traffic else None
         roof["note"] = ("avg launch duration = HIP-event time on the launch stream over the graph-replayed step launches / launches; "
-                        "it includes the ~1.5 us dependent-launch boundary")
+                        "it includes the ~1.5 us dependent-launch boundary; the working set lives in Infinity Cache (see residency), so "
+                        "frac is a nominal fraction of the HBM peak: the launch is latency-bound, not bandwidth-bound")
         line = {
             "metric": "walker-steps/sec + acceptance rate, 16384 walkers x 32 dims, 1/2/4/8 GPU",
             "value": walker_steps / elapsed,
@@ -573,6 +587,13 @@ def main():
                                  "time includes the stream-planning launches", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
                                  "de_update_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16> (+ de_boundary_kernel, one per 64 half-steps)", 2000,
                                  mover=capi.MOVER_DIFFERENTIAL_EVOLUTION, traffic_key="DE_C2", seconds=args.secondary_seconds),
+                # ParamType = float: the same two shapes at half the bytes per element
+                secondary_config(capi, workloads, local_rank, "C2's target in fp32 (SURVEY 8f row f4): 16384 walkers x 32 dims, correlated Gaussian, StretchMove, "
+                                 "ParamType = float; runs of 2000 ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
+                                 "stretch_full_step_kernel<float, DenseGaussianFn, EPL=4, LPW=8>", 2000, traffic_key="C2_f32", seconds=args.secondary_seconds, dtype=capi.F32),
+                secondary_config(capi, workloads, local_rank, "C5's ensemble in fp32 on ONE GPU: 131072 walkers x 64 dims, isotropic Gaussian, StretchMove, "
+                                 "ParamType = float; runs of 500 ensemble steps, nothing stored", 131072, 64, capi.CALC_ISO_GAUSSIAN, None,
+                                 "stretch_half_step_kernel<float, IsoGaussianFn, EPL=4, LPW=16>", 500, traffic_key="C5_one_gpu_f32", seconds=args.secondary_seconds, dtype=capi.F32),
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)

@@ -86,8 +86,13 @@ public:
             if (scan_run < 1) scan_run = 1;
             v = std::getenv("MCMCPP_HIP_DE_BATCH");  // half-steps planned together
             batch_max = (v && *v) ? (int)std::strtol(v, nullptr, 10) : kDeBatchMax;
-            v = std::getenv("MCMCPP_HIP_DE_DEBUG");  // timing diagnostics (the chain is wrong): 1 = the update launches alone, 2 = the planning launches alone
+#ifdef MCMCPP_DE_TIMING_DIAGNOSTICS
+            // Experiment builds only (make VARIANT=detiming EXTRA=-DMCMCPP_DE_TIMING_DIAGNOSTICS): launches left out to time
+            // the others -- THE CHAIN IS WRONG: 1 = the update launches alone, 2 = the planning launches alone, 3 / 4 / 5 = the
+            // boundary without its records / resolve / scan.  The library that ships has no such switch.
+            v = std::getenv("MCMCPP_HIP_DE_DEBUG");
             knob_debug = (v && *v) ? (int)std::strtol(v, nullptr, 10) : 0;
+#endif
         }
         // the batch: as many half-steps as the position counters (32 bits), the resolver's lists and a sensible amount of
         // record memory (256 MiB) allow

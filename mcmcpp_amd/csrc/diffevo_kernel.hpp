@@ -262,7 +262,7 @@ de_update_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>
     {
         const T margin = dev_abs(neg_exp - delta);
         const T scale = dev_abs(neg_exp) + dev_abs(lp_new) + dev_abs(lp_old);
-        if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+        if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
     }
     if (accept)
     {
@@ -402,7 +402,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
         {
             const T margin = dev_abs(neg_exp - delta);
             const T scale = dev_abs(neg_exp) + dev_abs(lp_new[q]) + dev_abs(lp_old[q]);
-            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+            if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
         if (accept)
         {

@@ -272,7 +272,7 @@ stretch_full_step_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* h
         {
             const T margin = dev_abs(rec.ln_u - delta);
             const T scale = dev_abs(rec.ln_u) + dev_abs(rec.zs) + dev_abs(lp_new) + dev_abs(lp_old);
-            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+            if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) fin[e] = accept ? prop[e] : own[e];
@@ -461,12 +461,25 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
 #pragma unroll
     for (int q = 0; q < 2; ++q)
     {
+#if defined(MCMCPP_EXP_PUSH) && (MCMCPP_EXP_PUSH & 1)
+        // EXPERIMENT 3i (timing only, THE CHAIN IS WRONG): what a push scheme would read -- the rows the records point to
+        // at addresses that follow from the walker's own index (an inbox of three rows per red/black pair), so that they
+        // go out with the first round trip instead of behind it
+        const int bx = (3 * ir[q]) & (h_n - 1);
+        load_row(pin, h_n + bx, par_r[q]);
+        const int jx = (bx + 1) & (h_n - 1);
+        rec_x[q] = dr_red[jx];
+        load_row(pin, jx, own_x[q]);
+        lp_x[q] = lin[jx];
+        load_row(pin, h_n + ((bx + 2) & (h_n - 1)), par_x[q]);
+#else
         load_row(pin, h_n + (int)rec_r[q].partner, par_r[q]);
         const int jx = (int)rec_b[q].partner;
         rec_x[q] = dr_red[jx];
         load_row(pin, jx, own_x[q]);
         lp_x[q] = lin[jx];
         load_row(pin, h_n + (int)rec_b[q].partner2, par_x[q]);
+#endif
     }
     // The wavefront's share of P^T: 8 x 16 bytes per lane, the same 8 KiB for every wavefront (L2 hits), through a preloaded
     // pointer (no kernarg miss in front).  Behind the second trip's loads on purpose: issued with the first trip they
@@ -494,7 +507,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         {
             const T margin = dev_abs(rec.ln_u - delta);
             const T scale = dev_abs(rec.ln_u) + dev_abs(rec.zs) + dev_abs(lp_new) + dev_abs(lp_old);
-            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+            if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
         fin[0] = accept ? prop[0] : own[0];
         fin[1] = accept ? prop[1] : own[1];
@@ -558,6 +571,10 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     {
         const bool accr = decide(q, own_r[q], prop4[2 + q], rec_r[q], lp_r[q], lp4[2 + q], true, fin, lp_fin) && active[q];
         commit(q, ir[q], fin, lp_fin, accr, nacc_r[q]);
+#if defined(MCMCPP_EXP_PUSH) && (MCMCPP_EXP_PUSH & 2)
+        // EXPERIMENT 3i: the red walker's final row pushed to the one consumer it has on average (a scattered inbox slot)
+        if (a.stamps != nullptr && col_ok) store_row_piece(reinterpret_cast<T*>(a.stamps) + (size_t)(3 * rec_r[q].partner + 1) * h_dims + i0, fin[0], fin[1]);
+#endif
         acc_red += (unsigned)__popcll(__ballot(accr && sub == 0));
     }
     MCMCPP_STAMP(3);  // red rows decided, their stores issued
@@ -568,6 +585,14 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     {
         const bool accb = decide(q, own_b[q], prop_b[q], rec_b[q], lp_b[q], lp_b_new[q], true, fin, lp_fin) && active[q];
         commit(q, h_n + ir[q], fin, lp_fin, accb, nacc_b[q]);
+#if defined(MCMCPP_EXP_PUSH) && (MCMCPP_EXP_PUSH & 2)
+        // EXPERIMENT 3i: the black walker's final row pushed to the two consumers it has on average
+        if (a.stamps != nullptr && col_ok)
+        {
+            store_row_piece(reinterpret_cast<T*>(a.stamps) + (size_t)(3 * rec_b[q].partner) * h_dims + i0, fin[0], fin[1]);
+            store_row_piece(reinterpret_cast<T*>(a.stamps) + (size_t)(3 * rec_b[q].partner2 + 2) * h_dims + i0, fin[0], fin[1]);
+        }
+#endif
         acc_blk += (unsigned)__popcll(__ballot(accb && sub == 0));
     }
     MCMCPP_STAMP(5);

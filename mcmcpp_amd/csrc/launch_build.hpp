@@ -34,13 +34,13 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
+    const size_t lds = ((size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);
 #define MCMCPP_LAUNCH_HALF_MC(DW, MC, THREADS)                                                                                                            \
     hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, DW, MC>), dim3(grid, chains), dim3(THREADS), lds, st, a.draws, a.pos, a.logp, a.n_accept, \
-                       a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a)
+                       a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a.calc_params_padded, a)
     if (a.draw_wave && chains > 1)
         MCMCPP_LAUNCH_HALF_MC(true, true, 64 * (kWavesPerBlock + 1));
     else if (a.draw_wave)

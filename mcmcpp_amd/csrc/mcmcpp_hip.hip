@@ -333,7 +333,8 @@ public:
         // Matrix-core variants of the half-step kernel (dense calculators, fp64, even D in 18..32): the wavefront's
         // walkers are rows of one MFMA tile -- 8 walkers (2 passes) until the chip is full, 16 (4 passes) beyond.
         const long mc_min = knobs.matrix_core_min_walkers;
-        if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min)
+        if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min &&
+            c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN)  // (they read the padded matrix this file prepares)
         {
             const int big = launch_walkers >= knobs.matrix_core_4pass ? 1 : 0;
             half_fn = table->half_step_mc[big][lpw_log][epl_shift];
@@ -447,6 +448,10 @@ public:
             d_jump_lo = reinterpret_cast<Affine128*>(piece + tables_offset_lo(n, have_task_table, K));
         }
         HIP_TRY(hipMemset(d_draws, 0, sizeof(DrawRec<T>) * (size_t)W * 2 * K));
+#if defined(MCMCPP_EXP_PUSH) && !defined(MCMCPP_STAMPS)
+        // experiment 3i (a variant build, never the library that ships): the scratch "inboxes" the pushed rows are written to
+        HIP_TRY(hipMalloc(&d_stamps, sizeof(T) * (size_t)3 * (size_t)n * (size_t)D + 4096));
+#endif
 #ifdef MCMCPP_STAMPS
         HIP_TRY(hipMalloc(&d_stamps, kStampWords * sizeof(unsigned long long)));  // [8 stamps][2 alternating launches][start, end of 4096 workgroups | end of their draw wavefronts]
         HIP_TRY(hipMemset(d_stamps, 0, kStampWords * sizeof(unsigned long long)));

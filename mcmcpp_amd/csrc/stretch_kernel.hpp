@@ -82,6 +82,16 @@ struct Diag
     unsigned long long redraws;
 };
 
+// An accept decision within a few ulp of a tie (include/mcmcpp_hip.h: near_ties).
+__device__ __forceinline__ void count_near_tie(Diag* diag)
+{
+#ifndef MCMCPP_EXP_NO_TIE_ATOMIC
+    atomicAdd(&diag->near_ties, 1ULL);
+#else
+    (void)diag;
+#endif
+}
+
 // The jump tables live right behind the draw records, at offsets that follow from the number of walkers per colour
 // alone, so that a kernel can reach them from its preloaded record pointer without touching the kernarg segment
 // (a draw wavefront's first loads would otherwise wait for a cold scalar miss):
@@ -229,6 +239,16 @@ __device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec
 {
     constexpr int VN = Vec16<T>::N;
     typedef typename Vec16<T>::type V;
+#ifdef MCMCPP_EXP_F32_BRANCHFREE
+    if constexpr (sizeof(T) == 4)
+    {
+        if (vec_ok)
+            load_slice_as<T, EPL, true>(row, i0, D, active, out);
+        else
+            load_slice_as<T, EPL, false>(row, i0, D, active, out);
+        return;
+    }
+#endif
 #pragma unroll
     for (int e = 0; e < EPL; ++e) out[e] = (T)0;
     if (!active) return;
@@ -924,7 +944,7 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         {
             const T margin = dev_abs(ln_u - delta);
             const T scale = dev_abs(ln_u) + dev_abs(zs) + dev_abs(lp_new) + dev_abs(lp_old);
-            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+            if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
         if (accept)
         {
@@ -1092,16 +1112,17 @@ __device__ __forceinline__ void mc_eval(const McB& B, double* sx, int sub, int g
 template <class T, class Calc, int EPL, int LPW, int P, bool DW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
-                              int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
+                              int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const T* hot_matrix, const HalfStepArgs<T> rest)
 {
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
     static_assert(P == 2 || P == 4, "two or four passes");
     constexpr int NW = 4 * P;   // walkers per wavefront
     constexpr int XS = kMcXS;
-    // LDS: [P^T zero-padded to 32 x 32 (workgroup)][proposal rows, NW x XS per wavefront]
+    // LDS: proposal rows, NW x XS per wavefront.  The wavefront's share of P^T (zero-padded to 32 x 32 by the host) comes
+    // straight from memory into registers through a preloaded pointer, as in the full-step kernel: no LDS copy of the
+    // matrix, no workgroup barrier (hot_matrix is the sixteenth preloaded dword pair).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_pt = reinterpret_cast<T*>(smem);
-    T* sh_x = sh_pt + 32 * 32 + (threadIdx.x >> 6) * (NW * XS);
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (NW * XS);
 
     const HalfStepArgs<T>& a = rest;
 #ifdef MCMCPP_STAMPS
@@ -1124,7 +1145,6 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     }
     const int h_color = (int)((hot_bits >> 20) & 1u);
     const int h_parity = (int)((hot_bits >> 24) & 1u);
-    constexpr bool h_draw_wave = DW;
     const DrawRec<T>* const h_draws = hot_draws + ((size_t)h_parity * 2 + (size_t)h_color) * (size_t)hot_n;
     DrawRec<T>* const h_draws_next = hot_draws + ((size_t)(1 - h_parity) * 2 + (size_t)h_color) * (size_t)hot_n;
     T* const h_pos = hot_pos;
@@ -1143,7 +1163,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         {
             // the workgroup's extra wavefront: next draws of every walker this workgroup updates
             draw_wave_body<T, 2>(a, jump_tables_behind(draws_chain0, hot_n, ((hot_bits >> 27) & 1u) != 0, chains), hot_ctl_in,
-                                 true /* the matrix barrier of the updating wavefronts */, h_draws_next, h_draws_next, 1, h_shard_begin,
+                                 false /* no workgroup barrier in this kernel */, h_draws_next, h_draws_next, 1, h_shard_begin,
                                  h_shard_count, blockIdx.x * kWavesPerBlock * NW, kWavesPerBlock * NW, lane, false, nullptr, -1, chain);
             return;
         }
@@ -1182,8 +1202,6 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         lp_old[q] = h_logp[w[q]];
         nacc_old[q] = h_n_accept[w[q]];  // every lane of the group reads the same word: no divergent branch, no wait
     }
-    typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);  // updating wavefronts only
 
     const StepCtl* ctl_mine = hot_ctl_in;
     const RunInfo* run_mine = a.run;
@@ -1198,12 +1216,15 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
     const bool direct_jump = a.task_jump != nullptr;
     Affine128 j_a, j_b;
-    if (direct_jump)
-        j_a = a.task_jump[3 * i_a + k_a];
-    else
+    if constexpr (!DW)
     {
-        j_a = a.jump_hi[i_a >> 8];
-        j_b = a.jump_lo[i_a & 255];
+        if (direct_jump)
+            j_a = a.task_jump[3 * i_a + k_a];
+        else
+        {
+            j_a = a.jump_hi[i_a >> 8];
+            j_b = a.jump_lo[i_a & 255];
+        }
     }
 
     // ---- second round trip: the partner rows of all passes ----------------------------------------------------------
@@ -1216,11 +1237,14 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         par[q][0] = (active[q] && col_ok) ? v.x : (T)0;
         par[q][1] = (active[q] && col_ok) ? v.y : (T)0;
     }
+    // the wavefront's share of P^T: 8 x 16 bytes per lane, the same 8 KiB for every wavefront (L2 hits), issued behind
+    // the partner gather so that it does not compete with the records the gather waits for
+    asm volatile("" ::: "memory");
+    McB matB;
+    mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);  // records landed, partner gather issued
 
-    // ---- in its shadow: the matrix goes to LDS, hand-over to the next launch, the walkers' next draws ----------------
-    Calc::block_commit(calc_pf, sh_pt, a.calc_params, h_dims, true, (int)threadIdx.x, 64 * kWavesPerBlock);
-    __syncthreads();
+    // ---- in its shadow: hand-over to the next launch, the walkers' next draws ------------------------------------------
     // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
     // in the extra wavefront it would lengthen the last wavefront to finish: measured)
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1231,13 +1255,17 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         save_slot = a.direct_save_slot;
     else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
-    if (!h_draw_wave && lane < 3 * NW && first + slot_a < h_shard_count)
-        compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
+    // Without a draw wavefront (16 walkers per wavefront) the walkers' next draws are made here, in the shadow of the
+    // gather.  (Behind the update instead -- fewer registers live across the tile, one more wavefront per SIMD -- the
+    // launch is 3 % shorter at 131 072 updates but 7 % longer at 65 536: profiles/r03_mc_probe_*.txt.)
+    if constexpr (!DW)
+    {
+        if (lane < 3 * NW && first + slot_a < h_shard_count)
+            compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
+    }
     MCMCPP_STAMP(2);  // next draws done
 
     // ---- proposals (StretchMove.h:105-108) -----------------------------------------------------------------------
-    McB matB;
-    mc_load_b(sh_pt, sub, grp, matB);
     T prop[P][2];
 #pragma unroll
     for (int q = 0; q < P; ++q)
@@ -1269,7 +1297,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         {
             const T margin = dev_abs(ln_u - delta);
             const T scale = dev_abs(ln_u) + dev_abs(zs) + dev_abs(lp_new[q]) + dev_abs(lp_old[q]);
-            if (margin <= a.tie_eps * scale) atomicAdd(&a.diag->near_ties, 1ULL);
+            if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
         T* row = h_pos + (size_t)w[q] * h_dims;
         if (accept)

@@ -67,6 +67,38 @@ def test_chains_stepped_together_equal_chains_stepped_alone(K, W, D, calc, pinne
     assert hip.counters()["accepted"] == 0
 
 
+def test_config4_eight_chains_of_c2_in_its_one_gpu_form():
+    """BASELINE config 4 exactly, on one GPU: 8 independent chains of 16 384 walkers x 32 dims, correlated Gaussian,
+    seeds 0..7 (the reference: eight EnsembleSampler objects, EnsembleSampler.h:199-218), stepped by the same launches.
+    Chain 0 is C2 itself and must reproduce the reference's own fixture `c2_16384x32`; chains 1..7 are checked against the
+    oracle."""
+    from tests.goldens import Golden
+    g = Golden("c2_16384x32")
+    K, W, D = 8, g.W, g.D
+    assert (W, D, g.seed, g.slicing) == (16384, 32, 0, 1)
+    orcs = []
+    for k in range(1, K):
+        orc = po.Oracle(W, D, po.CALC_DENSE_GAUSSIAN, g.params, seed=k)
+        pos = po.init_positions(po.F64, W, D, salt=k)
+        logp = orc.logp(pos)
+        orc.set_state(pos, logp)
+        orcs.append((orc, pos, logp))
+    hip = capi.HipSampler(W, D, po.CALC_DENSE_GAUSSIAN, g.params, seed=0, num_chains=K)
+    hip.set_state(np.stack([g.init_pos] + [o[1] for o in orcs]), np.stack([g.init_logp] + [o[2] for o in orcs]))
+    chain, acc = hip.run(g.steps)
+    for k in g.checked_steps:
+        if k >= 1:
+            g.check_chain_step(k, chain[0][k - 1])
+    np.testing.assert_array_equal(acc[0], g.accepted_per_call)
+    assert W + int(acc[0].sum()) == g.accepted_total  # (the reference counts the initial placement)
+    for k, (orc, _, _) in enumerate(orcs, start=1):
+        want_chain, want_acc = orc.run(g.steps, mode=po.MODE_COUNTER, threads=8)
+        np.testing.assert_array_equal(acc[k], want_acc, err_msg="chain %d" % k)
+        np.testing.assert_array_equal(chain[k], want_chain, err_msg="chain %d" % k)
+    c = hip.counters()
+    assert c["near_ties"] == 0 and c["redraws"] == 0 and c["ensemble_steps"] == g.steps
+
+
 def test_chains_config_is_checked():
     with pytest.raises(capi.HipError):  # too many
         capi.HipSampler(512, 8, po.CALC_ISO_GAUSSIAN, None, num_chains=17)

@@ -90,3 +90,54 @@ def test_plugin_functor_the_library_does_not_ship(plugin):
     assert np.abs(x.var(axis=0) * w - 1).max() < 0.08
     assert 0.3 < acc.mean() / W < 0.6
     assert s.counters()["near_ties"] == 0
+
+
+def _build_user_calculator_example():
+    """examples/user_calculator_device.hip -> libuser_calculator.so (hipcc), examples/user_calculator.cpp -> the program (g++)."""
+    capi.build_library()
+    build = os.path.dirname(OUT)
+    os.makedirs(build, exist_ok=True)
+    hdr_dir = os.path.join(ROOT, "mcmcpp_amd", "csrc")
+    dev_src = os.path.join(ROOT, "examples", "user_calculator_device.hip")
+    host_src = os.path.join(ROOT, "examples", "user_calculator.cpp")
+    dev_so = os.path.join(build, "libuser_calculator.so")
+    exe = os.path.join(build, "user_calculator")
+    newest_hdr = max(os.path.getmtime(os.path.join(hdr_dir, f)) for f in os.listdir(hdr_dir) if f.endswith((".hpp", ".inc")))
+    if not os.path.exists(dev_so) or os.path.getmtime(dev_so) < max(newest_hdr, os.path.getmtime(dev_src)):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+                               "-shared", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-I" + hdr_dir, dev_src, "-o", dev_so])
+    newest_inc = max(os.path.getmtime(os.path.join(dp, f)) for dp, _, fs in os.walk(os.path.join(ROOT, "include")) for f in fs)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(newest_inc, os.path.getmtime(host_src), os.path.getmtime(dev_so)):
+        subprocess.check_call(["g++", "-std=c++11", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include", "MCMCpp"),
+                               "-I" + os.path.join(ROOT, "include"), host_src, "-o", exe, "-L" + build, "-luser_calculator",
+                               "-L" + os.path.join(ROOT, "mcmcpp_amd"), "-lmcmcpp_hip", "-Wl,-rpath," + build,
+                               "-Wl,-rpath," + os.path.join(ROOT, "mcmcpp_amd")])
+    return exe
+
+
+def test_user_calculator_example_builds():
+    """CPU: the user's functor compiles against the plug-in header (hipcc cross-compiles) and the C++ program links."""
+    _build_user_calculator_example()
+
+
+@pytest.mark.gpu
+def test_user_calculator_through_the_cpp_facade(tmp_path):
+    """A host Calculator class of the user's own (hipCalcId = 1000) with its hipcc-built functor, run by
+    ParallelEnsembleSampler<double, StretchMove<double, UserClass>> (the reference's template surface,
+    /root/reference/MCMCpp/Movers/StretchMove.h:42-54): with means 0 / precisions 1 its chain must be the oracle's chain of
+    the isotropic Gaussian it then equals, stored step by stored step; with parameters of its own the program checks the
+    sample moments."""
+    exe = _build_user_calculator_example()
+    W, D, steps = 2048, 24, 60
+    pos = po.init_positions(po.F64, W, D, salt=6)
+    init = tmp_path / "init.bin"
+    init.write_bytes(pos.tobytes())
+    out_file = tmp_path / "chain.bin"
+    r = subprocess.run([exe, str(W), str(D), str(steps), str(init), str(out_file)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "user_calculator OK" in r.stdout and "identical chains" in r.stdout, r.stdout + r.stderr
+    chain = np.fromfile(out_file, dtype=np.float64).reshape(steps + 1, W, D)
+    orc = po.Oracle(W, D, po.CALC_ISO_GAUSSIAN, None, seed=0)
+    orc.set_state(pos, orc.logp(pos))
+    want, _ = orc.run(steps, mode=po.MODE_COUNTER, threads=4)
+    np.testing.assert_array_equal(chain[0], pos)
+    np.testing.assert_array_equal(chain[1:], want)

@@ -20,10 +20,12 @@ sys.path.insert(0, ROOT)
 
 # The secondary configurations of bench.py (its `secondary` list), by the substrings their step kernel's name carries.
 SECONDARY = {
-    "C3": ["stretch_half_step_kernel<", "RosenbrockFn"],
-    "C5_one_gpu": ["stretch_half_step_kernel<", "IsoGaussianFn"],
-    "C4_one_gpu": ["stretch_half_step_mfma_kernel<", "DenseGaussianFn"],
+    "C3": ["stretch_half_step_kernel<double", "RosenbrockFn"],
+    "C5_one_gpu": ["stretch_half_step_kernel<double", "IsoGaussianFn"],
+    "C4_one_gpu": ["stretch_half_step_mfma_kernel<double", "DenseGaussianFn"],
     "DE_C2": ["de_update_", "DenseGaussianFn"],
+    "C2_f32": ["stretch_full_step_kernel<float", "DenseGaussianFn"],
+    "C5_one_gpu_f32": ["stretch_half_step_kernel<float", "IsoGaussianFn"],
 }
 
 
