@@ -51,10 +51,15 @@ public:
             // the dense Gaussian's product on the matrix cores (de_update_mfma_kernel): fp64, even D, 8 walkers per wavefront
             const char* v = std::getenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS");
             const long mc_min = (v && *v) ? std::strtol(v, nullptr, 10) : 0;
-            if (table->de_update_mc[lpw_log][epl_shift] && c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN && D % 2 == 0 && mc_min >= 0 && n >= mc_min)
+            if (table->de_update_mc[0][lpw_log][epl_shift] && c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN && D % 2 == 0 && D <= 32 && mc_min >= 0 && n >= mc_min)
             {
-                update_fn = table->de_update_mc[lpw_log][epl_shift];
-                walkers_per_block = 8 * kWavesPerBlock;
+                // 16 walkers per wavefront once the chip is full (as the stretch kernels: MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS)
+                const char* v4 = std::getenv("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS");
+                const long four_pass = (v4 && *v4) ? std::strtol(v4, nullptr, 10) : 32768;
+                const int big = n >= four_pass ? 1 : 0;
+                update_fn = table->de_update_mc[big][lpw_log][epl_shift];
+                walkers_per_block = (big ? 16 : 8) * kWavesPerBlock;
+                matrix_core = true;
             }
         }
         calc_fn = table->calc[lpw_log][epl_shift];
@@ -136,7 +141,7 @@ public:
             HIP_TRY(hipEventCreate(&ev_t0[k]));
             HIP_TRY(hipEventCreate(&ev_t1[k]));
         }
-        graph_steps = c.graph_steps == 0 ? 128 : c.graph_steps;
+        graph_steps = c.graph_steps == 0 ? 128 : (c.graph_steps > 32768 ? 32768 : c.graph_steps);  // (the step inside a replay travels in 16 bits)
         // HIP cannot capture on the legacy default stream: a caller that hands it over gets plain launches
         if (!own_stream && (stream == nullptr || stream == hipStreamLegacy)) graph_steps = -1;
         replay_steps_max = graph_steps >= 1 ? graph_steps : 16;  // (plain launches: enqueued in groups of this many steps)
@@ -168,6 +173,15 @@ public:
             }
             HIP_TRY(hipMalloc(&d_params, sizeof(T) * prm.size()));
             HIP_TRY(hipMemcpy(d_params, prm.data(), sizeof(T) * prm.size(), hipMemcpyHostToDevice));
+            if (matrix_core)
+            {
+                // the matrix-core update kernels read P^T zero-padded to 32 x 32 straight into registers
+                std::vector<T> pad((size_t)32 * 32, (T)0);
+                for (int k = 0; k < D; ++k)
+                    for (int i = 0; i < D; ++i) pad[(size_t)k * 32 + i] = prm[(size_t)k * D + i];
+                HIP_TRY(hipMalloc(&d_params_padded, sizeof(T) * pad.size()));
+                HIP_TRY(hipMemcpy(d_params_padded, pad.data(), sizeof(T) * pad.size(), hipMemcpyHostToDevice));
+            }
         }
 
         // the stream (MultiSampler.h:54) and its jump tables: D + 3 draws per update
@@ -421,6 +435,7 @@ public:
         l.n = n;
         l.dims = D;
         l.vec_ok = vec_ok;
+        l.matrix_padded = d_params_padded;
         for (int i = 0; i < 2 * steps; ++i)
         {
             const uint64_t h = h0 + (uint64_t)i;
@@ -623,7 +638,7 @@ private:
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
         for (auto& kv : graph_cache)
             if (kv.second) (void)hipGraphExecDestroy(kv.second);
-        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_head, d_batch, d_run, d_counts, d_params, d_tables, d_chain, d_acc, d_recs, d_bad};
+        void* bufs[] = {d_pos, d_logp, d_nacc, d_diag, d_head, d_batch, d_run, d_counts, d_params, d_params_padded, d_tables, d_chain, d_acc, d_recs, d_bad};
         for (void* b : bufs)
             if (b) (void)hipFree(b);
         for (int k = 0; k < 2; ++k)
@@ -640,7 +655,8 @@ private:
     int W = 0, D = 0, n = 0, lpw = 1, epl = 1, vec_ok = 0, device = -1, walkers_per_block = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false, have_state = false;
-    T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_chain = nullptr;
+    T *d_pos = nullptr, *d_logp = nullptr, *d_params = nullptr, *d_params_padded = nullptr, *d_chain = nullptr;
+    bool matrix_core = false;
     uint32_t *d_nacc = nullptr, *d_acc = nullptr;
     Diag* d_diag = nullptr;
     DeHead* d_head = nullptr;

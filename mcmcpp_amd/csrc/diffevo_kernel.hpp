@@ -161,7 +161,10 @@ struct DeArgs
 };
 
 // hot_bits of de_update_kernel: dims | colour << 12 | vec_ok << 14
-__host__ __device__ inline uint32_t de_hot_bits(int dims, int color, int vec_ok) { return (uint32_t)dims | ((uint32_t)color << 12) | ((uint32_t)vec_ok << 14); }
+__host__ __device__ inline uint32_t de_hot_bits(int dims, int color, int vec_ok, int step = 0)
+{
+    return (uint32_t)dims | ((uint32_t)color << 12) | ((uint32_t)vec_ok << 14) | ((uint32_t)step << 16);
+}
 
 // ---- the update of one half-step ----------------------------------------------------------------------------------------
 // The hot_* arguments are what an updating wavefront needs before its second round trip; they travel in the 16 dwords
@@ -298,16 +301,17 @@ de_update_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>
 template <class T, class Calc, int EPL, int LPW, int P>
 __global__ void __launch_bounds__(64 * kWavesPerBlock)
 de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>* hot_recs, const Affine128* hot_jump_small, DeRunInfo* hot_run, int hot_n,
-                      uint32_t hot_bits, int hot_step, const DeArgs<T> a)
+                      uint32_t hot_bits, const T* hot_matrix, const DeArgs<T> a)
 {
     static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
     constexpr int NW = 4 * P;  // walkers per wavefront
-    constexpr int kThreads = 64 * kWavesPerBlock;
-    // LDS: [P^T zero-padded to 32 x 32 (workgroup)][proposal rows, NW x kMcXS per wavefront]
+    // LDS: proposal rows, NW x kMcXS per wavefront.  The wavefront's share of P^T (zero-padded to 32 x 32 by the host) comes
+    // straight from memory into registers through a preloaded pointer, as in the stretch kernels: no LDS copy of the
+    // matrix, no workgroup barrier.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_pt = reinterpret_cast<T*>(smem);
-    T* sh_x = sh_pt + 32 * 32 + (threadIdx.x >> 6) * (NW * kMcXS);
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (NW * kMcXS);
     const int dims = (int)(hot_bits & 0xFFFu), n = hot_n;
+    const int hot_step = (int)(hot_bits >> 16);  // ensemble step inside the graph replay
     const int lane = threadIdx.x & 63;
     const int color = (int)((hot_bits >> 12) & 1u);
     const int wave = (int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6);
@@ -344,8 +348,6 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
     void* const run_chain = assume_global(hot_run->chain);
     const long long run_slot0 = hot_run->slot0;
     const uint32_t run_interval = hot_run->interval, run_phase0 = hot_run->phase0;
-    typename Calc::Prefetch calc_pf;
-    Calc::block_prefetch(calc_pf, a.calc_params, dims, true, (int)threadIdx.x, kThreads);
 
     // second round trip: the two partner rows of every pass
     T w1[P][2], w2[P][2];
@@ -356,10 +358,12 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
         const V2 v2 = *reinterpret_cast<const V2*>(hot_pos + (size_t)(other_base + (active[q] ? (int)rec[q].ind2 : 0)) * dims + i0c);
         w1[q][0] = v1.x, w1[q][1] = v1.y, w2[q][0] = v2.x, w2[q][1] = v2.y;
     }
-    // in its shadow: the matrix goes to LDS, the lanes draw their jitters
-    Calc::block_commit(calc_pf, sh_pt, a.calc_params, dims, true, (int)threadIdx.x, kThreads);
-    __syncthreads();
+    // behind the gather (so that it does not compete with the records the gather waits for): the wavefront's share of P^T
+    asm volatile("" ::: "memory");
+    McB matB;
+    mc_load_b(hot_matrix, sub, grp, matB);
     if (!wave_active) return;
+    // in the gather's shadow: the lanes draw their jitters
 
     const uint32_t since = run_phase0 + (uint32_t)hot_step;
     const uint32_t whole = since / run_interval;
@@ -386,8 +390,6 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
             prop[q][e] = (active[q] && col_ok) ? p : (T)0;  // padded cells stay +0
         }
     }
-    McB matB;
-    mc_load_b(sh_pt, sub, grp, matB);
     T lp_new[P];
     mc_eval<P>(matB, sh_x, sub, grp, dims, prop, lp_new);
 

@@ -104,12 +104,13 @@ void launch_de(const typename LaunchTable<T>::DeLaunch& l, const DeArgs<T>& a, u
                        de_hot_bits(l.dims, l.color, l.vec_ok), l.step, a);
 }
 
-template <class T, class Calc, int EPL, int LPW>
+template <class T, class Calc, int EPL, int LPW, int P>
 void launch_de_mfma(const typename LaunchTable<T>::DeLaunch& l, const DeArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = (32 * 32 + (size_t)kWavesPerBlock * 4 * 2 * kMcXS) * sizeof(T);
-    hipLaunchKernelGGL((de_update_mfma_kernel<T, Calc, EPL, LPW, 2>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, l.pos, l.logp, l.n_accept, l.recs, l.jump_small, l.run,
-                       l.n, de_hot_bits(l.dims, l.color, l.vec_ok), l.step, a);
+    const size_t lds = ((size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
+    // (the step inside the replay travels in the hot bits: the sixteenth preloaded dword pair is the matrix pointer)
+    hipLaunchKernelGGL((de_update_mfma_kernel<T, Calc, EPL, LPW, P>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, l.pos, l.logp, l.n_accept, l.recs, l.jump_small, l.run,
+                       l.n, de_hot_bits(l.dims, l.color, l.vec_ok, l.step), l.matrix_padded, a);
 }
 
 template <class T, class Calc, int LPWLOG, int EPLSHIFT>
@@ -123,7 +124,8 @@ void put(LaunchTable<T>& t)
         t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
         t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
         t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
-        t.de_update_mc[LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
+        t.de_update_mc[0][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
+        t.de_update_mc[1][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
     }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     t.de_update[LPWLOG][EPLSHIFT] = &launch_de<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;

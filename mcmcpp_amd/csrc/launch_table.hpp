@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430016u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430017u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -43,12 +43,13 @@ struct LaunchTable
         const Affine128* jump_small;
         DeRunInfo* run;
         int n, dims, color, vec_ok;
-        int step;  // ensemble step inside the replay
+        int step;  // ensemble step inside the replay (< 65536)
+        const T* matrix_padded;  // matrix-core variants: P^T zero-padded to 32 x 32
     };
     typedef void (*DeFn)(const DeLaunch&, const DeArgs<T>&, unsigned grid, hipStream_t);
     DeFn de_update[kLpwLevels][kMaxEplShift];
-    // matrix-core variant (nullptr where the calculator has none): 8 walkers per wavefront, even D only
-    DeFn de_update_mc[kLpwLevels][kMaxEplShift];
+    // matrix-core variants (nullptr where the calculator has none): 8 ([0]) / 16 ([1]) walkers per wavefront, even D only
+    DeFn de_update_mc[2][kLpwLevels][kMaxEplShift];
 };
 
 // red_base != nullptr: black records, with partner2 (see DrawRec)

@@ -84,7 +84,8 @@ struct Knobs
     long matrix_core_min_walkers; // MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS  smallest shard stepped by the matrix-core kernels (0; -1: never)
     long matrix_core_4pass;       // MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS from this many walkers per half on: 16 walkers per wavefront (32768)
     long full_step;               // MCMCPP_HIP_FULL_STEP                1: one launch per ensemble step for small ensembles (1)
-    long full_step_max_walkers;   // MCMCPP_HIP_FULL_STEP_MAX_WALKERS    largest ensemble stepped that way (32768)
+    long full_step_max_walkers;   // MCMCPP_HIP_FULL_STEP_MAX_WALKERS    largest ensemble stepped that way (-1: 32768; 32767 where the matrix-core
+                                  //                                     half-step kernel is the alternative)
     long task_table_mb;           // MCMCPP_HIP_TASK_TABLE_MB            size limit of the one-entry-per-draw jump table (16)
     long chain_subchunk_mb;       // MCMCPP_HIP_CHAIN_SUBCHUNK_MB        device chain staging per sub-chunk / ring budget (32)
     long graph_steps;             // MCMCPP_HIP_GRAPH_STEPS              ensemble steps per hipGraph replay (-1 here: 300 up to 32768 walkers, else 128)
@@ -108,7 +109,7 @@ struct Knobs
         k.matrix_core_min_walkers = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
         k.matrix_core_4pass = env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768);
         k.full_step = env_long("MCMCPP_HIP_FULL_STEP", 1);
-        k.full_step_max_walkers = env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", 32768);
+        k.full_step_max_walkers = env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", -1);
         k.task_table_mb = env_long("MCMCPP_HIP_TASK_TABLE_MB", 16);
         k.chain_subchunk_mb = env_long("MCMCPP_HIP_CHAIN_SUBCHUNK_MB", 32);
         k.graph_steps = env_long("MCMCPP_HIP_GRAPH_STEPS", -1);
@@ -347,8 +348,12 @@ public:
         // so the ranks exchange rows once per ensemble step), by the size of what it updates.
         full_fn = nullptr;
         const bool whole = shard_count == n && shard_begin == 0;
+        // (measured, 32 dims fp64, us per ensemble step full / half: isotropic 32 768 walkers 7 % in favour of full steps;
+        //  dense with the matrix-core half-step kernel 10.75 / 10.06 at 32 768, 5.47 / 7.28 at 16 384: profiles/r03_mc_probe_e.txt)
+        const bool mc_half = table->half_step_mc[0][lpw_log][epl_shift] && half_fn == table->half_step_mc[launch_walkers >= knobs.matrix_core_4pass ? 1 : 0][lpw_log][epl_shift];
+        const long full_step_max = knobs.full_step_max_walkers >= 0 ? knobs.full_step_max_walkers : (mc_half ? 32767 : 32768);
         if ((c.comm_world >= 1 ? (knobs.comm_full_step != 0 && knobs.full_step != 0) : (whole && knobs.full_step != 0)) &&
-            2 * launch_walkers <= knobs.full_step_max_walkers)
+            2 * launch_walkers <= full_step_max)
         {
             full_fn = table->full_step[lpw_log][epl_shift];
             full_wpb = kWavesPerBlock * (64 / lpw);

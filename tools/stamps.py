@@ -10,11 +10,14 @@ from mcmcpp_amd import workloads
 names = ["entry->partner gather issued", "tables+next draws", "wait partner rows", "calculator", "accept+stores issued"]
 if os.environ.get("MCMCPP_HIP_FULL_STEP", "1") != "0":  # full-step kernels (full_step_kernel.hpp)
     names = ["entry->2nd trip issued", "->tile 1 done (x|red)", "red decide+stores", "black tile", "black decide+stores"]
-for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
-    D = 32
+# python tools/stamps.py [calc W D f64|f32] ...   (default: the three C2-sized cases)
+cases = [("iso", 16384, 32, "f64"), ("dense", 16384, 32, "f64"), ("iso", 128, 32, "f64")]
+if len(sys.argv) > 1:
+    cases = [(sys.argv[i], int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3]) for i in range(1, len(sys.argv), 4)]
+for calc, W, D, dtype in cases:
     P = workloads.ar1_precision(D, 0.5)
     cid, prm = {"dense": (capi.CALC_DENSE_GAUSSIAN, P.ravel()), "iso": (capi.CALC_ISO_GAUSSIAN, None)}[calc]
-    s = capi.HipSampler(W, D, cid, prm, seed=0)
+    s = capi.HipSampler(W, D, cid, prm, seed=0, dtype=capi.F32 if dtype == "f32" else capi.F64)
     pos = workloads.init_positions(W, D)
     s.set_state(pos, s.calc_logp(pos))
     acc = []
@@ -35,7 +38,7 @@ for calc, W in [("iso", 16384), ("dense", 16384), ("iso", 128)]:
     sets.sort(key=lambda x: x[0][:, 0].min() if len(x[0]) else 0)   # earlier launch first
     prev, (blk, dw) = sets[0], sets[1]
     d = np.median(np.array(acc), axis=0)
-    print(calc, W, " | ".join("%s %.0f" % (n, x) for n, x in zip(names, d[:5])), "| total %.0f ticks (s_memtime) | shader clock ~%.0f MHz" % (d[:5].sum(), d[5]))
+    print(calc, W, D, dtype, " | ".join("%s %.0f" % (n, x) for n, x in zip(names, d[:5])), "| total %.0f ticks (s_memtime) | shader clock ~%.0f MHz" % (d[:5].sum(), d[5]))
     if len(blk):
         t0 = blk[:, 0].min()
         st, en = (blk[:, 0] - t0) * 10, (blk[:, 1] - t0) * 10   # ns on the 100 MHz clock
