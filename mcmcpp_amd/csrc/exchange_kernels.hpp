@@ -55,16 +55,21 @@ __global__ void __launch_bounds__(256) exchange_sync_seen_kernel(const uint32_t*
     seen[w] = n_accept[w] & kAcceptCountMask;
 }
 
-// One lane per walker of the slice (colours [color0, color0 + colors)); a wavefront reserves slots for its moved walkers
-// with one atomic, then copies their rows with all 64 lanes.  The block's count must be zero on entry (the scatter
-// kernel of the previous exchange, or the host at the start of a chunk, sees to that).
+// A wavefront looks at kPackWalkersPerWave walkers of the slice (colours [color0, color0 + colors)), one per lane of its
+// first lanes, reserves slots for those that moved with one atomic, and copies their rows with all 64 lanes -- few
+// walkers per wavefront on purpose: the rows of a wavefront go one after the other (each a dependent load -> store), so
+// the launch is as long as the busiest wavefront's list (16 384 walkers at 16 % moved: 64 per wavefront 8.8 us, 16 per
+// wavefront about a third of that).  The block's count must be zero on entry (the scatter kernel of the previous
+// exchange, or the host at the start of a chunk, sees to that).
+constexpr int kPackWalkersPerWave = 16;
 template <class T>
 __global__ void __launch_bounds__(256) exchange_pack_kernel(const T* pos, const T* logp, const uint32_t* n_accept, uint32_t* seen, char* block, uint32_t cap,
                                                             int n, int dims, int shard_begin, int shard_count, int color0, int colors)
 {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = i < colors * shard_count;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int i = wave * kPackWalkersPerWave + lane;
+    const bool in_range = lane < kPackWalkersPerWave && i < colors * shard_count;
     const int w = in_range ? (color0 + i / shard_count) * n + shard_begin + i % shard_count : 0;
     bool moved = false;
     if (in_range)

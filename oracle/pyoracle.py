@@ -70,6 +70,9 @@ def lib():
         for f in ("so_half_steps_done", "so_near_ties", "so_redraws"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = C.c_uint64
+        L.so_seek.argtypes = [C.c_void_p, C.c_uint64]
+        L.so_last_near_tie.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]
         L.so_half_step_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
         L.so_half_step_commit.argtypes = [C.c_void_p]
         L.so_chain_covariance.argtypes = [C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
@@ -206,6 +209,17 @@ class Oracle:
     def logp_view(self):
         buf = (C.c_char * (self.W * np.dtype(self.np_t).itemsize)).from_address(lib().so_logp_ptr(self.h))
         return np.frombuffer(buf, dtype=self.np_t)
+
+    def seek(self, ensemble_steps_done):
+        """Position the random stream as if that many ensemble steps had been executed since set_state (StretchMove)."""
+        assert lib().so_seek(self.h, ensemble_steps_done) == 0
+
+    def last_near_tie(self):
+        """(half-step, walker, accepted, ln U, delta) of the most recent near tie, or None."""
+        hs, w, a, u, d = C.c_uint64(0), C.c_uint32(0), C.c_int32(0), C.c_double(0), C.c_double(0)
+        if lib().so_last_near_tie(self.h, C.byref(hs), C.byref(w), C.byref(a), C.byref(u), C.byref(d)) != 0:
+            return None
+        return hs.value, w.value, bool(a.value), u.value, d.value
 
     @property
     def near_ties(self):

@@ -93,6 +93,14 @@ static void run_case(int dtype, int W, int D, int calc, int mover)
     CHECK(so_get_state(s, pos, logp, nacc) == 0);
     (void)so_near_ties(s);
     (void)so_redraws(s);
+    {
+        uint64_t hs = 0;
+        uint32_t w = 0;
+        int32_t acc = 0;
+        double lu = 0, dl = 0;
+        (void)so_last_near_tie(s, &hs, &w, &acc, &lu, &dl); /* (-1: there has been none) */
+        (void)so_seek(s, so_half_steps_done(s) / 2);
+    }
     so_destroy(s);
     /* analysis restatements over the stored steps */
     void* mean = malloc((size_t)D * es);

@@ -140,6 +140,11 @@ struct so_sampler {
     uint64_t half_steps;
     uint64_t near_ties;
     uint64_t redraws;
+    /* the most recent near tie (so_last_near_tie): which decision it was */
+    uint64_t tie_half_step;
+    uint32_t tie_walker;
+    int32_t tie_accepted;
+    double tie_ln_u, tie_delta;
 };
 
 #define REAL double
@@ -308,6 +313,24 @@ int so_get_state(so_sampler* s, void* positions, void* logp, uint32_t* n_accept)
 
 uint64_t so_half_steps_done(const so_sampler* s) { return s ? s->half_steps : 0; }
 uint64_t so_near_ties(const so_sampler* s) { return s ? s->near_ties : 0; }
+
+int so_seek(so_sampler* s, uint64_t ensemble_steps_done)
+{
+    if (!s || s->cfg.mover != SO_MOVER_STRETCH) return -1; /* (differential evolution: the position depends on the draws thrown away) */
+    s->half_steps = 2 * ensemble_steps_done;
+    return 0;
+}
+
+int so_last_near_tie(const so_sampler* s, uint64_t* half_step, uint32_t* walker, int32_t* accepted, double* ln_u, double* delta)
+{
+    if (!s || s->near_ties == 0) return -1;
+    if (half_step) *half_step = s->tie_half_step;
+    if (walker) *walker = s->tie_walker;
+    if (accepted) *accepted = s->tie_accepted;
+    if (ln_u) *ln_u = s->tie_ln_u;
+    if (delta) *delta = s->tie_delta;
+    return 0;
+}
 uint64_t so_redraws(const so_sampler* s) { return s ? s->redraws : 0; }
 
 int so_chain_covariance(int32_t dtype, const void* steps, int64_t n_steps, int32_t walkers, int32_t dims, int32_t slice,

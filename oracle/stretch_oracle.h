@@ -98,6 +98,12 @@ int so_get_state(so_sampler* s, void* positions, void* logp, uint32_t* n_accept)
 uint64_t so_half_steps_done(const so_sampler* s);
 /* decisions whose margin |lnU - delta| was within a few ulp: a different libm `log` could flip them */
 uint64_t so_near_ties(const so_sampler* s);
+/* the most recent of them: the half-step (counted from set_state / so_seek's origin), the walker (0 .. W-1), the decision
+ * taken and the two sides of the comparison; -1 when there has been none */
+int so_last_near_tie(const so_sampler* s, uint64_t* half_step, uint32_t* walker, int32_t* accepted, double* ln_u, double* delta);
+/* StretchMove only: position the random stream as if `ensemble_steps_done` steps had been executed since set_state
+ * (what mcmcpp_hip_seek does on the device): a checkpointed ensemble can be stepped on from any step */
+int so_seek(so_sampler* s, uint64_t ensemble_steps_done);
 /* bounded_rand rejections (only possible when W/2 is not a power of two) */
 uint64_t so_redraws(const so_sampler* s);
 
