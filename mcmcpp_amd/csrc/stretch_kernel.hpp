@@ -76,6 +76,20 @@ struct alignas(16) DrawRec
                        // red partner in the same ensemble step, so that both rows can be fetched in one round trip
 };
 
+// What a half-step update uses of its record.  The kernels keep THIS across their pass loop, not the 32-byte record: a
+// copied DrawRec<float> (20 bytes of fields, 12 of padding, partner2 unused here) is not taken apart into registers -- its
+// unused half stays a private array, which the back end "promotes" to LDS, and a kernel with such an array reads the
+// workgroup size from the dispatch packet (host memory) at the start of every wavefront: 13-28 us per fp32 half-step
+// launch where fp64 took 3-10 (round 3; profiles/r03_fp32_half_step_anomaly.txt).
+template <class T>
+struct DrawUse
+{
+    T z, zs, ln_u;
+    uint32_t partner;
+    __device__ __forceinline__ DrawUse() {}
+    __device__ __forceinline__ DrawUse(const DrawRec<T>& r) : z(r.z), zs(r.zs), ln_u(r.ln_u), partner(r.partner) {}
+};
+
 struct Diag
 {
     unsigned long long near_ties;
@@ -239,16 +253,6 @@ __device__ __forceinline__ void load_slice(const T* row, int i0, int D, bool vec
 {
     constexpr int VN = Vec16<T>::N;
     typedef typename Vec16<T>::type V;
-#ifdef MCMCPP_EXP_F32_BRANCHFREE
-    if constexpr (sizeof(T) == 4)
-    {
-        if (vec_ok)
-            load_slice_as<T, EPL, true>(row, i0, D, active, out);
-        else
-            load_slice_as<T, EPL, false>(row, i0, D, active, out);
-        return;
-    }
-#endif
 #pragma unroll
     for (int e = 0; e < EPL; ++e) out[e] = (T)0;
     if (!active) return;
@@ -802,12 +806,12 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
     T own[EPL];
     T lp_old;
     uint32_t nacc_old = 0;
-    DrawRec<T> rec;
+    DrawUse<T> rec;
     {
         const int li0 = first + grp;
         const bool act0 = wave_active && li0 < h_shard_count;
         const int w0 = half_base + h_shard_begin + (act0 ? li0 : 0);
-        rec = h_draws[w0 - half_base];  // the 16 (LPW) lanes of a walker read the same 32 bytes: one transaction
+        rec = DrawUse<T>(h_draws[w0 - half_base]);  // the LPW lanes of a walker read the same bytes: one transaction
         load_slice<T, EPL>(h_pos + (size_t)w0 * h_dims, i0, h_dims, vec_ok, act0, own);
         lp_old = h_logp[w0];
         nacc_old = h_n_accept[w0];  // every lane of the group reads the same word: no divergent branch, no wait
@@ -909,13 +913,13 @@ stretch_half_step_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_
         T own_next[EPL];
         T lp_next = (T)0;
         uint32_t nacc_next = 0;
-        DrawRec<T> rec_next = rec;
+        DrawUse<T> rec_next = rec;
         if (q + 1 < h_passes)
         {
             const int lin = li + WPP;
             const bool actn = lin < h_shard_count;
             const int wn = half_base + h_shard_begin + (actn ? lin : 0);
-            rec_next = h_draws[wn - half_base];
+            rec_next = DrawUse<T>(h_draws[wn - half_base]);
             load_slice<T, EPL>(h_pos + (size_t)wn * h_dims, i0, h_dims, vec_ok, actn, own_next);
             lp_next = h_logp[wn];
             nacc_next = h_n_accept[wn];
