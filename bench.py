@@ -173,6 +173,58 @@ def residency_note(W, D, elem, chains=1, buffers=1):
     return "positions %.0f MiB: beyond Infinity Cache, served by HBM" % mib
 
 
+def live_counter_traffic(kernel_sub, seconds_per_pass=90.0):
+    """HBM bytes per launch of the headline step kernel measured IN THIS RUN: two child processes, each this very script
+    (2 bench steps, nothing else) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, the
+    program itself behind `--`, never combined with another trace domain, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
+    doubled (gfx950 counts 128-byte read requests at 64 bytes), both counters are KiB per dispatch.  Runs behind the timed
+    region.  Returns (bytes per launch, note) or (None, why): a missing profiler, a pass that fails or overruns its time
+    limit (the child is killed by its own process id) simply leaves the committed figure in place."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None, "this run is itself being profiled"
+    means = {}
+    tmp = tempfile.mkdtemp(prefix="mcmcpp_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+                env.pop(k, None)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-live-counters"]
+            child = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            try:
+                rc = child.wait(timeout=seconds_per_pass)
+            except subprocess.TimeoutExpired:
+                child.kill()
+                child.wait()
+                return None, "the %s pass overran %.0f s" % (counter, seconds_per_pass)
+            if rc != 0:
+                return None, "the %s pass ended with code %d" % (counter, rc)
+            vals = []
+            for path in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if r["Counter_Name"] == counter and kernel_sub in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, "no %s rows for %s" % (counter, kernel_sub)
+            means[counter] = (sum(vals) / len(vals), len(vals))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = (2.0 * means["FETCH_SIZE"][0] + means["WRITE_SIZE"][0]) * 1024.0
+    return total, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over "
+                   "`bench.py --steps 2` (%d / %d dispatches of the step kernel); 2 x FETCH_SIZE + WRITE_SIZE, KiB per dispatch, "
+                   "FETCH_SIZE doubled per the gfx950 correction" % (means["FETCH_SIZE"][1], means["WRITE_SIZE"][1]))
+
+
 def roofline_of(W, D, walker_steps, launches, gpu_ms, kernel, saved_fraction=0.0, rows_read=2, elem=8, chains=1):
     """(2D+1)*s read + (D+1)*s written per walker update (+ D*s when the step is stored), s = element size
     (8: fp64, 4: fp32), times the walker updates one launch performs, over the average launch duration (HIP events on the
@@ -405,6 +457,9 @@ def main():
                     help="stored steps into a pinned block from the library (MCMCPP_CHAIN_MEMORY=pinned in the facade): the launches "
                          "write them in place, no staging ring, no host copy")
     ap.add_argument("--no-accepted", action="store_true", help="experiments only: skip the per-step accepted counters")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="do not measure roofline.traffic in this run (two short rocprofv3 --pmc child passes behind the timed region); "
+                         "the committed counter file is reported instead while it matches the sources")
     ap.add_argument("--mode", default="chains", choices=["chains", "split"],
                     help="chains (default, the headline): one independent C2 chain per GPU; split: BASELINE config 5, "
                          "one 131072x64 ensemble split over the GPUs, exchanged over RCCL by the library")
@@ -414,7 +469,7 @@ def main():
                     help="--mode split on ONE GPU: that many ranks as threads of this process, exchanging through the test-only loop-back "
                          "collective library (tests/cpp/loopback_ccl.hip) -- a rehearsal of the world > 1 code path")
     ap.add_argument("--no-split-leg", action="store_true", help="several ranks: skip the bounded C5 (split ensemble) measurement behind the chains")
-    ap.add_argument("--split-leg-seconds", type=float, default=20.0, help="several ranks: time limit of that measurement")
+    ap.add_argument("--split-leg-seconds", type=float, default=45.0, help="several ranks: time limit of that measurement")
     ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
                     help="experiments only: the headline workload is the dense (correlated) Gaussian")
     args = ap.parse_args()
@@ -597,6 +652,17 @@ def main():
             ]
         if world == 1 and not args.no_cpu_baseline and args.calc == "dense":
             line["cpu_baseline"] = cpu_baseline(W, D, P, args.cpu_sample_steps)
+        if world == 1 and not args.no_live_counters and args.calc == "dense" and (W, D) == (16384, 32) and not args.no_chain:
+            # the counters of THIS run (the committed file stays as the fallback and as the secondary lines' source)
+            sampler.close()
+            torch.cuda.synchronize()
+            live, note = live_counter_traffic(kernel.split("<")[0])
+            if live is not None:
+                roof["traffic_committed"] = roof["traffic"]
+                roof["traffic"] = live
+                roof["traffic_source"] = note
+            else:
+                roof["traffic_live"] = "not taken (%s); the committed counter file is reported" % note
     else:
         line = None
 

@@ -5,5 +5,5 @@ try:
 except Exception as e: print(sys.argv[2],'FAILED',e)
 " $1 $2; }
 for calc in rosenbrock iso dense; do for W in 32768 65536 131072; do for fs in 1 0; do
-  MCMCPP_HIP_FULL_STEP=$fs MCMCPP_HIP_FULL_STEP_MAX_WALKERS=100000000 timeout -k 10 120 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --calc $calc --walkers $W --batch 250 --interval 250 > gpurun_out/c3_$fs.json 2>/dev/null; p gpurun_out/c3_$fs.json ${calc}_${W}_full$fs
+  MCMCPP_HIP_FULL_STEP=$fs MCMCPP_HIP_FULL_STEP_MAX_WALKERS=100000000 timeout -k 10 120 python bench.py --no-live-counters --steps 6 --warmup 2 --no-cpu-baseline --no-chain --calc $calc --walkers $W --batch 250 --interval 250 > gpurun_out/c3_$fs.json 2>/dev/null; p gpurun_out/c3_$fs.json ${calc}_${W}_full$fs
 done; done; done

@@ -8,5 +8,5 @@ except Exception as e: print(sys.argv[2],'FAILED',e)
 " $1 $2; }
 for tag in "$@"; do
   lib=$PWD/mcmcpp_amd/libmcmcpp_hip_$tag.so; [ "$tag" = base ] && lib=$PWD/mcmcpp_amd/libmcmcpp_hip.so
-  MCMCPP_HIP_FULL_STEP=0 MCMCPP_HIP_LIB=$lib timeout -k 10 120 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --calc iso --walkers 65536 --batch 250 --interval 250 > gpurun_out/libh_$tag.json 2> gpurun_out/libh_$tag.err; p gpurun_out/libh_$tag.json $tag
+  MCMCPP_HIP_FULL_STEP=0 MCMCPP_HIP_LIB=$lib timeout -k 10 120 python bench.py --no-live-counters --steps 6 --warmup 2 --no-cpu-baseline --no-chain --calc iso --walkers 65536 --batch 250 --interval 250 > gpurun_out/libh_$tag.json 2> gpurun_out/libh_$tag.err; p gpurun_out/libh_$tag.json $tag
 done

@@ -8,6 +8,6 @@ except Exception as e: print(sys.argv[2],'FAILED',e)
 " $1 $2; }
 for fs in 1 0; do
  for calc in dense iso rosenbrock; do
-  MCMCPP_HIP_FULL_STEP=$fs timeout -k 10 120 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --calc $calc > gpurun_out/ab_${fs}_$calc.json 2> gpurun_out/ab_${fs}_$calc.err; p gpurun_out/ab_${fs}_$calc.json full${fs}_${calc}
+  MCMCPP_HIP_FULL_STEP=$fs timeout -k 10 120 python bench.py --no-live-counters --steps 8 --warmup 2 --no-cpu-baseline --calc $calc > gpurun_out/ab_${fs}_$calc.json 2> gpurun_out/ab_${fs}_$calc.err; p gpurun_out/ab_${fs}_$calc.json full${fs}_${calc}
  done
 done

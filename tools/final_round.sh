@@ -6,10 +6,10 @@ tag=$1
 if [ "$2" != "extras" ]; then
 tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1
 echo "profile done"
-python bench.py --steps 100 --no-cpu-baseline --no-secondary --pinned-chain > gpurun_out/bench_${tag}_pinned.json 2>/dev/null
-python bench.py --mode split > gpurun_out/split_${tag}_full.json 2>/dev/null
-python bench.py --mode split --split-walkers 16384 > gpurun_out/split_${tag}_rank.json 2>/dev/null
-MCMCPP_HIP_COMM_FULL_STEP=0 python bench.py --mode split --split-walkers 16384 > gpurun_out/split_${tag}_rank_half.json 2>/dev/null
+python bench.py --no-live-counters --steps 100 --no-cpu-baseline --no-secondary --pinned-chain > gpurun_out/bench_${tag}_pinned.json 2>/dev/null
+python bench.py --no-live-counters --mode split > gpurun_out/split_${tag}_full.json 2>/dev/null
+python bench.py --no-live-counters --mode split --split-walkers 16384 > gpurun_out/split_${tag}_rank.json 2>/dev/null
+MCMCPP_HIP_COMM_FULL_STEP=0 python bench.py --no-live-counters --mode split --split-walkers 16384 > gpurun_out/split_${tag}_rank_half.json 2>/dev/null
 echo "split done"
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_de -- python tools/bench_diffevo.py 16384 32 500 > gpurun_out/prof_${tag}_de.log 2>&1
 fi
