@@ -150,11 +150,12 @@ struct DenseGaussianFn
 {
     static constexpr bool kNeedsStage = true;
     static constexpr int kMaxPadded = 64;
-    // fp64 walkers of 17..32 dimensions take the matrix-core kernel (stretch_half_step_mfma_kernel)
+    // walkers of 17..32 dimensions take the matrix-core kernels (stretch_half_step_mfma_kernel): the slot of that range
+    // is 16 lanes x 2 elements for fp64, 8 lanes x 4 elements for fp32
     template <int EPL, int LPW>
     struct MatrixCore
     {
-        static constexpr bool kUse = sizeof(T) == 8 && EPL == 2 && LPW == 16;
+        static constexpr bool kUse = (sizeof(T) == 8 && EPL == 2 && LPW == 16) || (sizeof(T) == 4 && EPL == 4 && LPW == 8);
     };
 
     __host__ __device__ static int padded_dim(int D)

@@ -303,13 +303,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock)
 de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>* hot_recs, const Affine128* hot_jump_small, DeRunInfo* hot_run, int hot_n,
                       uint32_t hot_bits, const T* hot_matrix, const DeArgs<T> a)
 {
-    static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
+    static_assert(EPL == 2 && LPW == 16, "matrix-core path: 16 lanes x 2 elements per walker, 16 < D <= 32");
     constexpr int NW = 4 * P;  // walkers per wavefront
     // LDS: proposal rows, NW x kMcXS per wavefront.  The wavefront's share of P^T (zero-padded to 32 x 32 by the host) comes
     // straight from memory into registers through a preloaded pointer, as in the stretch kernels: no LDS copy of the
     // matrix, no workgroup barrier.
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (NW * kMcXS);
+    constexpr int kStageRows = sizeof(T) == 8 ? NW : 16;  // rows of the tile that hold walkers (mc_row)
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (kStageRows * kMcXS);
     const int dims = (int)(hot_bits & 0xFFFu), n = hot_n;
     const int hot_step = (int)(hot_bits >> 16);  // ensemble step inside the graph replay
     const int lane = threadIdx.x & 63;
@@ -320,7 +321,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
     const int half_base = color ? n : 0, other_base = color ? 0 : n;
     const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
     // (the host only selects this kernel for even D: rows are whole 16-byte pieces, every access is branch-free)
-    typedef double2 V2;
+    typedef typename Vec2<T>::type V2;
     const bool col_ok = i0 < dims;
     const int i0c = col_ok ? i0 : 0;
 
@@ -360,7 +361,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
     }
     // behind the gather (so that it does not compete with the records the gather waits for): the wavefront's share of P^T
     asm volatile("" ::: "memory");
-    McB matB;
+    McB<T> matB;
     mc_load_b(hot_matrix, sub, grp, matB);
     if (!wave_active) return;
     // in the gather's shadow: the lanes draw their jitters
@@ -408,7 +409,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
         }
         if (accept)
         {
-            if (col_ok) *reinterpret_cast<V2*>(hot_pos + (size_t)w[q] * dims + i0) = make_double2(prop[q][0], prop[q][1]);
+            if (col_ok) *reinterpret_cast<V2*>(hot_pos + (size_t)w[q] * dims + i0) = Vec2<T>::make(prop[q][0], prop[q][1]);
             if (sub == 0)
             {
                 hot_logp[w[q]] = lp_new[q];
@@ -418,7 +419,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
         if (save_slot >= 0 && active[q] && col_ok)
         {
             T* crow = reinterpret_cast<T*>(run_chain) + ((size_t)save_slot * (size_t)(2 * n) + (size_t)w[q]) * dims;
-            *reinterpret_cast<V2*>(crow + i0) = accept ? make_double2(prop[q][0], prop[q][1]) : make_double2(own[q][0], own[q][1]);
+            *reinterpret_cast<V2*>(crow + i0) = accept ? Vec2<T>::make(prop[q][0], prop[q][1]) : Vec2<T>::make(own[q][0], own[q][1]);
         }
         acc += (unsigned)__popcll(__ballot(accept && sub == 0));
     }

@@ -353,17 +353,26 @@ __device__ __forceinline__ void store_row_piece(double* p, double x0, double x1)
     const v2d v = {x0, x1};
     store_through16(p, v);
 }
+// (fp32: 8 bytes of a row)
+__device__ __forceinline__ void store_row_piece(float* p, float x0, float x1)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = {x0, x1};
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
 
 template <class T, class Calc, int EPL, int LPW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
 stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, int hot_sh_begin, int hot_sh_count, int hot_n,
                               uint32_t hot_bits, const StepCtl* hot_ctl_in, const HalfStepArgs<T> rest)
 {
-    static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
+    static_assert(EPL == 2 && LPW == 16, "matrix-core path: 16 lanes x 2 elements per walker, 16 < D <= 32");
     constexpr int NW = 8;  // walkers of each colour per wavefront
-    // LDS: per updating wavefront one 16-row and one 8-row staging area of proposals
+    // LDS: per updating wavefront one 16-row staging area of proposals and one for the second tile (8 rows in fp64, whose
+    // walkers sit in rows 4q + g; 16 in fp32: rows 4g + q, see mc_row)
+    constexpr int kSecondTileRows = sizeof(T) == 8 ? NW : 2 * NW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (3 * NW * kMcXS);
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * ((2 * NW + kSecondTileRows) * kMcXS);
 
     const HalfStepArgs<T>& a = rest;
 #ifdef MCMCPP_STAMPS
@@ -420,7 +429,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     const int first = wave * NW;  // (relative to the shard)
     if (first >= sh_count) return;  // (no workgroup barrier in this kernel)
     const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
-    typedef double2 V2;
+    typedef typename Vec2<T>::type V2;
     const bool col_ok = i0 < h_dims;  // (even D only: rows are whole 16-byte pieces)
     const int i0c = col_ok ? i0 : 0;
     // Unconditional 16-byte loads from always-valid addresses, no masking: lanes beyond D re-read the row's first
@@ -485,7 +494,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // pointer (no kernarg miss in front).  Behind the second trip's loads on purpose: issued with the first trip they
     // compete with every wavefront's record loads, which the second trip waits for (5.76 -> 5.60 us per launch).
     asm volatile("" ::: "memory");
-    McB matB;
+    McB<T> matB;
     mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);
     // every scalar miss of this wavefront in one batch whose wait overlaps the second round trip (see the plain kernel)
@@ -528,7 +537,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         if (save_slot >= 0 && col_ok)
         {
             T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * h_n) + (size_t)w) * h_dims;
-            *reinterpret_cast<V2*>(crow + i0) = make_double2(fin[0], fin[1]);
+            *reinterpret_cast<V2*>(crow + i0) = Vec2<T>::make(fin[0], fin[1]);
         }
     };
 

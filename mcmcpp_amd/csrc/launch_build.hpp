@@ -34,7 +34,7 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = ((size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
+    const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS) * sizeof(T);
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);
@@ -70,7 +70,7 @@ void launch_full(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 template <class T, class Calc, int EPL, int LPW>
 void launch_full_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = ((size_t)kWavesPerBlock * 3 * 8 * kMcXS) * sizeof(T);
+    const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 3 : 4) * 8 * kMcXS) * sizeof(T);
     const int chains = a.chains > 1 ? a.chains : 1;
     // (the colour bit, meaningless for a full step, says that the draw records were made ahead: HalfStepArgs::draw_wave == 2;
     //  such a launch has one extra wavefront per workgroup, the forwarder of stored steps, instead of the draw wavefronts)
@@ -107,7 +107,7 @@ void launch_de(const typename LaunchTable<T>::DeLaunch& l, const DeArgs<T>& a, u
 template <class T, class Calc, int EPL, int LPW, int P>
 void launch_de_mfma(const typename LaunchTable<T>::DeLaunch& l, const DeArgs<T>& a, unsigned grid, hipStream_t st)
 {
-    const size_t lds = ((size_t)kWavesPerBlock * 4 * P * kMcXS) * sizeof(T);
+    const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS) * sizeof(T);
     // (the step inside the replay travels in the hot bits: the sixteenth preloaded dword pair is the matrix pointer)
     hipLaunchKernelGGL((de_update_mfma_kernel<T, Calc, EPL, LPW, P>), dim3(grid), dim3(64 * kWavesPerBlock), lds, st, l.pos, l.logp, l.n_accept, l.recs, l.jump_small, l.run,
                        l.n, de_hot_bits(l.dims, l.color, l.vec_ok, l.step), l.matrix_padded, a);
@@ -121,11 +121,13 @@ void put(LaunchTable<T>& t)
     t.full_step[LPWLOG][EPLSHIFT] = &launch_full<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     if constexpr (Calc::template MatrixCore<(kBase << EPLSHIFT), (1 << LPWLOG)>::kUse)
     {
-        t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
-        t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
-        t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
-        t.de_update_mc[0][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 2>;
-        t.de_update_mc[1][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG), 4>;
+        // (the matrix-core kernels always map a walker to 16 lanes x 2 elements, whatever the slot's own mapping -- for
+        //  fp32 walkers of 17..32 dimensions the slot is 8 lanes x 4 elements)
+        t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, 2, 16, 2>;
+        t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, 2, 16, 4>;
+        t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, 2, 16>;
+        t.de_update_mc[0][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, 2, 16, 2>;
+        t.de_update_mc[1][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, 2, 16, 4>;
     }
     t.calc[LPWLOG][EPLSHIFT] = &launch_calc<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;
     t.de_update[LPWLOG][EPLSHIFT] = &launch_de<T, Calc, (kBase << EPLSHIFT), (1 << LPWLOG)>;

@@ -331,6 +331,7 @@ public:
         }
         if (passes < 1) passes = 1;
         if (passes > lpw) passes = lpw;
+        step_lpw = lpw;  // lanes per walker of the step kernels in use
         // Matrix-core variants of the half-step kernel (dense calculators, fp64, even D in 18..32): the wavefront's
         // walkers are rows of one MFMA tile -- 8 walkers (2 passes) until the chip is full, 16 (4 passes) beyond.
         const long mc_min = knobs.matrix_core_min_walkers;
@@ -340,6 +341,7 @@ public:
             const int big = launch_walkers >= knobs.matrix_core_4pass ? 1 : 0;
             half_fn = table->half_step_mc[big][lpw_log][epl_shift];
             passes = big ? 4 : 2;
+            step_lpw = 16;  // (the matrix-core kernels map a walker to 16 lanes x 2 elements in either element type)
         }
 
         // One launch per ensemble step (full_step_kernel.hpp) while the ensemble is small enough that a half-step
@@ -1549,7 +1551,7 @@ private:
     unsigned grid_blocks() const { return grid_blocks_for(shard_count); }
     unsigned grid_blocks_for(int count) const
     {
-        const long per_wave = (long)(64 / lpw) * passes;
+        const long per_wave = (long)(64 / step_lpw) * passes;
         const long waves = (count + per_wave - 1) / per_wave;
         return (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     }
@@ -1613,7 +1615,7 @@ private:
         a.calc_params_padded = d_params_padded;
         a.chains = (K == 1 && knobs.force_multi_chain_kernels != 0) ? -1 : K;
         // a fifth wavefront per workgroup computes the next draws when that is at most two rounds of 64 draws
-        a.draw_wave = (3 * kWavesPerBlock * (64 / lpw) * passes <= 128 && knobs.no_draw_wave == 0) ? 1 : 0;
+        a.draw_wave = (3 * kWavesPerBlock * (64 / step_lpw) * passes <= 128 && knobs.no_draw_wave == 0) ? 1 : 0;
         return a;
     }
 
@@ -1911,7 +1913,7 @@ private:
     T* d_pos_alt = nullptr;
     uint64_t run_step = 0;                                  // ensemble steps enqueued in the current run()
     typename LaunchTable<T>::CalcFn calc_fn = nullptr;
-    int W = 0, D = 0, n = 0, lpw = 1, epl = 1, passes = 1, vec_ok = 0, num_cus = 256;
+    int W = 0, D = 0, n = 0, lpw = 1, epl = 1, step_lpw = 1, passes = 1, vec_ok = 0, num_cus = 256;
     int shard_begin = 0, shard_count = 0, device = -1, graph_steps = 32;
     size_t chain_subchunk_bytes = 0, chain_half_capacity = 0, acc_capacity = 0;
     hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_filled[2] = {nullptr, nullptr};

@@ -1061,54 +1061,91 @@ __global__ void __launch_bounds__(192) fill_draws_batch_kernel(const HalfStepArg
 // 4q + g, so its result comes back in register q of the very lanes that apply the accept.
 // ---------------------------------------------------------------------------------------------------------
 typedef double mfma_f64x4 __attribute__((ext_vector_type(4)));
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kMcXS = 34;  // row stride of staged proposals (doubles): even (16-byte rows), = 2 mod 16 to spread LDS banks
+constexpr int kMcXS = 34;  // row stride of staged proposals (elements): even (whole 2-element pieces), = 2 mod 16 to spread LDS banks
+
+// two consecutive elements of a row (what a lane of the matrix-core kernels holds of a walker: 16 lanes x 2 elements)
+template <class T>
+struct Vec2;
+template <>
+struct Vec2<double>
+{
+    typedef double2 type;
+    __device__ __forceinline__ static double2 make(double a, double b) { return make_double2(a, b); }
+};
+template <>
+struct Vec2<float>
+{
+    typedef float2 type;
+    __device__ __forceinline__ static float2 make(float a, float b) { return make_float2(a, b); }
+};
+
+// Row of the 16-row tile that walker (pass q, lane group g) occupies: chosen so that its result comes back in register q
+// of the lanes of group g, which apply the accept.  The two instructions lay their results out differently
+// (tools/mfma_probe.hip, tools/mfma_f32_probe.hip): v_mfma_f64_16x16x4_f64 lane l, register r -> [m = 4r + l/16][n = l%16];
+// v_mfma_f32_16x16x4_f32 lane l, register r -> [m = 4(l/16) + r][n = l%16].  Both are, bit for bit, the fma chain in
+// ascending k starting from the C operand -- the host Calculator's loop.
+template <class T>
+__device__ __forceinline__ int mc_row(int q, int g)
+{
+    return sizeof(T) == 8 ? 4 * q + g : 4 * g + q;
+}
 
 // The wavefront's share of P^T, held in registers for the whole launch: for k-step ks, B[k = 4ks + lane/16][n] with
 // tile column n of y0 = matrix column 2n and of y1 = matrix column 2n + 1, so that the product comes back in the
 // very lanes (and element order) that hold the proposal: lane (grp, sub) holds x[2 sub], x[2 sub + 1].
+template <class T>
 struct McB
 {
-    double2 b[8];
+    typename Vec2<T>::type b[8];
 };
-__device__ __forceinline__ void mc_load_b(const double* sh_pt, int sub, int grp, McB& B)
+template <class T>
+__device__ __forceinline__ void mc_load_b(const T* sh_pt, int sub, int grp, McB<T>& B)
 {
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) B.b[ks] = *reinterpret_cast<const double2*>(sh_pt + (4 * ks + grp) * 32 + 2 * sub);
+    for (int ks = 0; ks < 8; ++ks) B.b[ks] = *reinterpret_cast<const typename Vec2<T>::type*>(sh_pt + (4 * ks + grp) * 32 + 2 * sub);
 }
 
-// log-posteriors -1/2 x^T P x of the 4P proposals prop[q] (q < P; row 4q + grp of the tile), one MFMA tile:
+__device__ __forceinline__ mfma_f64x4 mc_mfma(double a, double b, mfma_f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ mfma_f32x4 mc_mfma(float a, float b, mfma_f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// log-posteriors -1/2 x^T P x of the 4P proposals prop[q] (q < P; row mc_row(q, grp) of the tile), one MFMA tile:
 // Y = X * P^T in 8 k-steps, k ascending (the host's fma order), then t_j = x_j * y_j and the canonical tree
-// (in-lane pair, then the 16-lane butterfly).  `sx` is a wave-private staging area of 4P x kMcXS doubles.
-template <int P>
-__device__ __forceinline__ void mc_eval(const McB& B, double* sx, int sub, int grp, int dims, const double (&prop)[P][2], double (&lp)[P])
+// (in-lane pair, then the 16-lane butterfly).  `sx` is a wave-private staging area of 16 x kMcXS elements (4P x kMcXS
+// for fp64, whose rows 4q + g stay below 4P).
+template <int P, class T>
+__device__ __forceinline__ void mc_eval(const McB<T>& B, T* sx, int sub, int grp, int dims, const T (&prop)[P][2], T (&lp)[P])
 {
+    typedef typename std::conditional<sizeof(T) == 8, mfma_f64x4, mfma_f32x4>::type Acc;
 #pragma unroll
-    for (int q = 0; q < P; ++q) *reinterpret_cast<double2*>(sx + (4 * q + grp) * kMcXS + 2 * sub) = make_double2(prop[q][0], prop[q][1]);
+    for (int q = 0; q < P; ++q) *reinterpret_cast<typename Vec2<T>::type*>(sx + mc_row<T>(q, grp) * kMcXS + 2 * sub) = Vec2<T>::make(prop[q][0], prop[q][1]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double xa[8];
+    // A[m = lane%16][k = 4ks + lane/16]; rows without a walker read as +0 (fp64: rows >= 4P; fp32: registers >= P of a group)
+    const bool row_used = sizeof(T) == 8 ? sub < 4 * P : (sub & 3) < P;
+    T xa[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) xa[ks] = (sub < 4 * P) ? sx[sub * kMcXS + 4 * ks + grp] : 0.0;  // A[m = lane%16][k = 4ks + lane/16]
-    mfma_f64x4 y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
+    for (int ks = 0; ks < 8; ++ks) xa[ks] = row_used ? sx[sub * kMcXS + 4 * ks + grp] : (T)0;
+    Acc y0 = {0, 0, 0, 0}, y1 = {0, 0, 0, 0};
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
     {
-        y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], B.b[ks].x, y0, 0, 0, 0);
-        y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[ks], B.b[ks].y, y1, 0, 0, 0);
+        y0 = mc_mfma(xa[ks], B.b[ks].x, y0);
+        y1 = mc_mfma(xa[ks], B.b[ks].y, y1);
     }
     const bool in = 2 * sub < dims;  // D is even: both of the lane's elements or neither
 #pragma unroll
     for (int r = 0; r < P; ++r)
     {
-        const double t0 = prop[r][0] * y0[r], t1 = prop[r][1] * y1[r];
-        double t = in ? t0 + t1 : 0.0;
+        const T t0 = prop[r][0] * y0[r], t1 = prop[r][1] * y1[r];
+        T t = in ? t0 + t1 : (T)0;
         t = t + dpp_move<0xB1>(t);
         t = t + dpp_move<0x4E>(t);
         t = t + dpp_move<0x141>(t);
         t = t + dpp_move<0x140>(t);
-        lp[r] = -0.5 * t;
+        lp[r] = (T)-0.5 * t;
     }
 }
 
@@ -1118,15 +1155,16 @@ __global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const T* hot_matrix, const HalfStepArgs<T> rest)
 {
-    static_assert(sizeof(T) == 8 && EPL == 2 && LPW == 16, "matrix-core path: fp64, 16 < D <= 32");
+    static_assert(EPL == 2 && LPW == 16, "matrix-core path: 16 lanes x 2 elements per walker, 16 < D <= 32");
     static_assert(P == 2 || P == 4, "two or four passes");
     constexpr int NW = 4 * P;   // walkers per wavefront
     constexpr int XS = kMcXS;
+    constexpr int kStageRows = sizeof(T) == 8 ? NW : 16;  // rows of the tile that hold walkers (mc_row)
     // LDS: proposal rows, NW x XS per wavefront.  The wavefront's share of P^T (zero-padded to 32 x 32 by the host) comes
     // straight from memory into registers through a preloaded pointer, as in the full-step kernel: no LDS copy of the
     // matrix, no workgroup barrier (hot_matrix is the sixteenth preloaded dword pair).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (NW * XS);
+    T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (kStageRows * XS);
 
     const HalfStepArgs<T>& a = rest;
 #ifdef MCMCPP_STAMPS
@@ -1178,8 +1216,8 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     const int half_base = h_color ? h_n : 0;
     const int other_base = h_color ? 0 : h_n;
     const int sub = lane & 15, grp = lane >> 4, i0 = sub * 2;
-    // (the host only selects this kernel for even D: rows are whole 16-byte pieces, every access is branch-free)
-    typedef double2 V2;
+    // (the host only selects this kernel for even D: rows are whole 2-element pieces, every access is branch-free)
+    typedef typename Vec2<T>::type V2;
     const bool col_ok = i0 < h_dims;
     const int i0c = col_ok ? i0 : 0;
     const int last_li = h_shard_count - 1;
@@ -1244,7 +1282,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // the wavefront's share of P^T: 8 x 16 bytes per lane, the same 8 KiB for every wavefront (L2 hits), issued behind
     // the partner gather so that it does not compete with the records the gather waits for
     asm volatile("" ::: "memory");
-    McB matB;
+    McB<T> matB;
     mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);  // records landed, partner gather issued
 
@@ -1306,7 +1344,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         T* row = h_pos + (size_t)w[q] * h_dims;
         if (accept)
         {
-            if (col_ok) *reinterpret_cast<V2*>(row + i0) = make_double2(prop[q][0], prop[q][1]);
+            if (col_ok) *reinterpret_cast<V2*>(row + i0) = Vec2<T>::make(prop[q][0], prop[q][1]);
             if (sub == 0)
             {
                 h_logp[w[q]] = lp_new[q];
@@ -1317,7 +1355,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         {
             T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * h_n) + (size_t)w[q]) * h_dims;
             if (col_ok)
-                *reinterpret_cast<V2*>(crow + i0) = accept ? make_double2(prop[q][0], prop[q][1]) : make_double2(own[q][0], own[q][1]);
+                *reinterpret_cast<V2*>(crow + i0) = accept ? Vec2<T>::make(prop[q][0], prop[q][1]) : Vec2<T>::make(own[q][0], own[q][1]);
         }
         accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
     }

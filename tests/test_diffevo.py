@@ -128,8 +128,15 @@ def test_device_differential_evolution_resumes_across_calls():
     # BASELINE's larger ensembles (several planning batches each) and the widest walker the kernels are built for
     (65536, 32, po.CALC_ROSENBROCK, [1.0, 100.0, 0.05], po.F64, 70, 35), (131072, 64, po.CALC_ISO_GAUSSIAN, None, po.F64, 3, 1),
     (2200, 1024, po.CALC_ISO_GAUSSIAN, None, po.F64, 6, 1),
+    # the dense Gaussian on the matrix cores in both element types: 8 walkers per wavefront, a ragged last wavefront, and
+    # 16 per wavefront (from 32 768 walkers per half)
+    (1030, 32, po.CALC_DENSE_GAUSSIAN, "ar1", po.F64, 30, 1), (1030, 26, po.CALC_DENSE_GAUSSIAN, "ar1", po.F32, 30, 1),
+    (65536 + 20, 32, po.CALC_DENSE_GAUSSIAN, "ar1", po.F32, 4, 1), (65536 + 20, 32, po.CALC_DENSE_GAUSSIAN, "ar1", po.F64, 4, 1),
 ])
 def test_device_differential_evolution_matches_the_oracle(W, D, calc, params, dt, steps, interval):
+    if isinstance(params, str):
+        from mcmcpp_amd import workloads
+        params = workloads.ar1_precision(D, 0.5).ravel()
     pos = po.init_positions(dt, W, D, salt=6)
     orc = po.Oracle(W, D, calc, params, seed=21, dtype=dt, mover=po.MOVER_DIFFERENTIAL_EVOLUTION)
     lp = orc.logp(pos)

@@ -99,11 +99,17 @@ def _oracle_and_hip(W, D, calc, dtype, seed, steps, interval=1, salt=3, **kw):
     return orc, hip
 
 
-def _assert_same_state(orc, hip):
+def _assert_same_state(orc, hip, ties_expected=False):
+    """ties_expected: fp32 runs of a few hundred thousand updates meet decisions inside the guard band (6e-7 of the
+    magnitudes involved -- about one update in 10^5); the chains are compared bit for bit all the same, and device and
+    oracle must have flagged equally many."""
     for a, b, what in zip(hip.get_state(), orc.get_state(), ("positions", "logp", "n_accept")):
         np.testing.assert_array_equal(a, b, err_msg=what)
     c = hip.counters()
-    assert c["near_ties"] == 0 == orc.near_ties and c["redraws"] == orc.redraws == 0
+    if ties_expected:
+        assert c["near_ties"] == orc.near_ties and c["redraws"] == orc.redraws == 0
+    else:
+        assert c["near_ties"] == 0 == orc.near_ties and c["redraws"] == orc.redraws == 0
 
 
 @pytest.mark.parametrize("W,D,calc,dtype,steps,interval", [
@@ -171,17 +177,37 @@ def test_resume_reset_and_unsaved_runs_are_seamless(step_path):
     assert int(nacc.sum()) == int(oa[30:].sum())               # counters restarted at the reset
 
 
+@pytest.mark.parametrize("dtype", [po.F64, po.F32])
 @pytest.mark.parametrize("W,D", [(4096 + 6, 32), (600, 18), (2048, 26)])
-def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D, step_path):
-    """The f64 MFMA variants of the step kernels against the oracle, including ragged last wavefronts and padded
-    dimensions (17 <= D <= 32, even)."""
+def test_matrix_core_kernel_is_bit_exact(monkeypatch, W, D, dtype, step_path):
+    """The MFMA variants of the step kernels against the oracle, including ragged last wavefronts and padded
+    dimensions (17 <= D <= 32, even): v_mfma_f64_16x16x4_f64 and, since round 3, v_mfma_f32_16x16x4_f32 (both are the
+    host calculator's fma chain in ascending k: tools/mfma_probe.hip, tools/mfma_f32_probe.hip)."""
     monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "0")
-    orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, po.F64, seed=77, steps=0)
+    orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, dtype, seed=77, steps=0)
     oc, oa = orc.run(30, interval=2, mode=po.MODE_COUNTER, threads=4)
     hc, ha = hip.run(30, interval=2)
     np.testing.assert_array_equal(ha, oa)
     np.testing.assert_array_equal(hc, oc)
-    _assert_same_state(orc, hip)
+    _assert_same_state(orc, hip, ties_expected=dtype == po.F32)
+
+
+def test_matrix_core_kernels_with_sixteen_walkers_per_wavefront_fp32(monkeypatch):
+    """The 16-walkers-per-wavefront matrix-core half-step kernel in fp32 (rows 4g + q of the tile: every register of a lane
+    group in use), with a ragged last wavefront, and against the plain fp32 kernels (MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS=-1)."""
+    monkeypatch.setenv("MCMCPP_HIP_FULL_STEP", "0")
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", "1")
+    orc, hip = _oracle_and_hip(8192 + 10, 32, po.CALC_DENSE_GAUSSIAN, po.F32, seed=3, steps=0)
+    oc, oa = orc.run(12, interval=2, mode=po.MODE_COUNTER, threads=4)
+    hc, ha = hip.run(12, interval=2)
+    np.testing.assert_array_equal(ha, oa)
+    np.testing.assert_array_equal(hc, oc)
+    _assert_same_state(orc, hip, ties_expected=True)
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "-1")
+    orc2, plain = _oracle_and_hip(8192 + 10, 32, po.CALC_DENSE_GAUSSIAN, po.F32, seed=3, steps=0)
+    pc, pa = plain.run(12, interval=2)
+    np.testing.assert_array_equal(pc, hc)
+    np.testing.assert_array_equal(pa, ha)
 
 
 @pytest.mark.parametrize("batch", ["0", "1", "7", "128"])
