@@ -645,7 +645,7 @@ def main():
                 # ParamType = float: the same two shapes at half the bytes per element
                 secondary_config(capi, workloads, local_rank, "C2's target in fp32 (SURVEY 8f row f4): 16384 walkers x 32 dims, correlated Gaussian, StretchMove, "
                                  "ParamType = float; runs of 2000 ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
-                                 "stretch_full_step_kernel<float, DenseGaussianFn, EPL=4, LPW=8>", 2000, traffic_key="C2_f32", seconds=args.secondary_seconds, dtype=capi.F32),
+                                 "stretch_full_step_mfma_kernel<float, DenseGaussianFn, EPL=2, LPW=16>", 2000, traffic_key="C2_f32", seconds=args.secondary_seconds, dtype=capi.F32),
                 secondary_config(capi, workloads, local_rank, "C5's ensemble in fp32 on ONE GPU: 131072 walkers x 64 dims, isotropic Gaussian, StretchMove, "
                                  "ParamType = float; runs of 500 ensemble steps, nothing stored", 131072, 64, capi.CALC_ISO_GAUSSIAN, None,
                                  "stretch_half_step_kernel<float, IsoGaussianFn, EPL=4, LPW=16>", 500, traffic_key="C5_one_gpu_f32", seconds=args.secondary_seconds, dtype=capi.F32),

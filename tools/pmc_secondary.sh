@@ -11,5 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_${tag}_$c -- python bench.py --no-live-counters --steps 2 --warmup 1 --no-cpu-baseline --secondary-seconds 0.2 > gpurun_out/pmc_${tag}_$c.log 2>&1
   echo "$c pass done"
 done
-python tools/pmc_traffic.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE stretch_full_step_mfma_kernel gpurun_out/pmc_traffic_$tag.json "C2 16384x32 dense Gaussian, one launch per ensemble step (python bench.py --no-live-counters --steps 2 --warmup 1 --secondary-seconds 0.2); secondary: the step kernels of bench.py's secondary configurations in the same passes"
+python tools/pmc_traffic.py /tmp/pmc_${tag}_FETCH_SIZE /tmp/pmc_${tag}_WRITE_SIZE "stretch_full_step_mfma_kernel<double" gpurun_out/pmc_traffic_$tag.json "C2 16384x32 dense Gaussian, one launch per ensemble step (python bench.py --no-live-counters --steps 2 --warmup 1 --secondary-seconds 0.2); secondary: the step kernels of bench.py's secondary configurations in the same passes"
 { python tools/pmc.py /tmp/pmc_${tag}_FETCH_SIZE; python tools/pmc.py /tmp/pmc_${tag}_WRITE_SIZE; } > gpurun_out/pmc_${tag}_summary.txt

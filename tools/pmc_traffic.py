@@ -24,7 +24,7 @@ SECONDARY = {
     "C5_one_gpu": ["stretch_half_step_kernel<double", "IsoGaussianFn"],
     "C4_one_gpu": ["stretch_half_step_mfma_kernel<double", "DenseGaussianFn"],
     "DE_C2": ["de_update_", "DenseGaussianFn"],
-    "C2_f32": ["stretch_full_step_kernel<float", "DenseGaussianFn"],
+    "C2_f32": ["stretch_full_step_mfma_kernel<float", "DenseGaussianFn"],
     "C5_one_gpu_f32": ["stretch_half_step_kernel<float", "IsoGaussianFn"],
 }
 
