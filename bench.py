@@ -173,7 +173,7 @@ def residency_note(W, D, elem, chains=1, buffers=1):
     return "positions %.0f MiB: beyond Infinity Cache, served by HBM" % mib
 
 
-def live_counter_traffic(kernel_sub, seconds_per_pass=90.0):
+def live_counter_traffic(kernel_sub, seconds_per_pass=60.0):
     """HBM bytes per launch of the headline step kernel measured IN THIS RUN: two child processes, each this very script
     (2 bench steps, nothing else) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` -- separate passes, the
     program itself behind `--`, never combined with another trace domain, as MI355X_MICROARCH.md prescribes; FETCH_SIZE
