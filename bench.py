@@ -275,41 +275,27 @@ def secondary_config(capi, workloads, device, name, W, D, calc, params, kernel, 
 LOOPBACK_LIB = os.path.join(ROOT, "tests", "cpp", "_build", "libloopback_ccl.so")
 
 
-def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, warmup, loopback_ranks=0):
-    """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling.
-    Every rank owns one handle with an RCCL communicator: mcmcpp_hip_run enqueues the step launches and the exchanges.
-    Returns the measurement (rank 0; None elsewhere).
+SPLIT_STEPS_PER = 50  # ensemble steps per bench step of the split measurement
 
-    loopback_ranks = G > 0 (rehearsals on a one-GPU box; MCMCPP_HIP_RCCL_LIB must name tests/cpp/loopback_ccl's library before
-    the library binds its collectives): G ranks as G threads of THIS process, all on this process's GPU -- the product's
-    world > 1 code with a loop-back exchange; throughput figures then describe G ranks sharing one GPU, not a G-GPU job."""
+
+def split_rank_numbers(args, capi, torch, local_rank, G, ranks_here, cid, steps, warmup, sync):
+    """Steps C5's ensemble as rank(s) `ranks_here` of G (one rank: this process is that rank; several: loop-back ranks as threads
+    of this process) and returns {rank: raw numbers}.  sync(): what brackets the timed loop besides the library's own
+    collectives (which keep the ranks in lockstep anyway)."""
     import threading
     from mcmcpp_amd import workloads
     W, D = args.split_walkers, 64
-    steps_per = 50
-    G = loopback_ranks if loopback_ranks > 0 else world
-    with _StdoutToStderr():  # (RCCL's banner)
-        if world > 1 and loopback_ranks == 0:
-            box = [capi.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            cid = box[0]
-        else:
-            cid = capi.comm_unique_id()
+    steps_per = SPLIT_STEPS_PER
     pos = workloads.init_positions(W, D, salt=0)
     probe = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, device=local_rank)
     logp = probe.calc_logp(pos)
     probe.close()
-
-    def outer_barrier():
-        if dist is not None and loopback_ranks == 0:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    thread_barrier = threading.Barrier(G) if loopback_ranks > 0 else None
+    threaded = len(ranks_here) > 1
+    thread_barrier = threading.Barrier(len(ranks_here)) if threaded else None
     results = {}
 
     def one_rank(r):
-        with (_Nothing() if loopback_ranks > 0 else _StdoutToStderr()):
+        with (_Nothing() if threaded else _StdoutToStderr()):  # (RCCL's banner)
             ens = capi.HipSampler(W, D, capi.CALC_ISO_GAUSSIAN, None, seed=0, device=local_rank, comm_world=G, comm_rank=r, comm_id=cid)
         ens.set_state(pos, logp)
         for _ in range(warmup):
@@ -318,7 +304,7 @@ def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, w
         if thread_barrier is not None:
             thread_barrier.wait()
         else:
-            outer_barrier()
+            sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             _, acc = ens.run(1, interval=steps_per, save_chain=False)
@@ -336,12 +322,12 @@ def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, w
         if thread_barrier is not None:
             thread_barrier.wait()
         else:
-            outer_barrier()
+            sync()
         results[r] = dict(elapsed=time.perf_counter() - t0, accepted=accepted, gpu_ms=gpu_ms, launches=launches, enq_ms=enq_ms,
                           xchg_us=xchg_us, xbytes=xbytes / steps, repeats=repeats, slots=slots)
         ens.close()
 
-    if loopback_ranks > 0:
+    if threaded:
         errs = []
 
         def guarded(r):
@@ -349,19 +335,44 @@ def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, w
                 one_rank(r)
             except Exception as e:  # noqa: BLE001
                 errs.append("rank %d: %s" % (r, e))
-                if thread_barrier is not None:
-                    thread_barrier.abort()
-        threads = [threading.Thread(target=guarded, args=(r,)) for r in range(G)]
+                thread_barrier.abort()
+        threads = [threading.Thread(target=guarded, args=(r,)) for r in ranks_here]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
         if errs:
             raise RuntimeError("; ".join(errs))
-        mine = results[0]
     else:
-        one_rank(rank)
-        mine = results[rank]
+        one_rank(ranks_here[0])
+    return results
+
+
+def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, warmup, loopback_ranks=0):
+    """BASELINE config 5: one 131 072-walker x 64-dim isotropic-Gaussian ensemble over all ranks; strong scaling.
+    Every rank owns one handle with an RCCL communicator: mcmcpp_hip_run enqueues the step launches and the exchanges.
+    Returns the measurement (rank 0; None elsewhere).
+
+    loopback_ranks = G > 0 (rehearsals on a one-GPU box; MCMCPP_HIP_RCCL_LIB must name tests/cpp/loopback_ccl's library before
+    the library binds its collectives): G ranks as G threads of THIS process, all on this process's GPU -- the product's
+    world > 1 code with a loop-back exchange; throughput figures then describe G ranks sharing one GPU, not a G-GPU job."""
+    G = loopback_ranks if loopback_ranks > 0 else world
+    with _StdoutToStderr():  # (RCCL's banner)
+        if world > 1 and loopback_ranks == 0:
+            box = [capi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            cid = box[0]
+        else:
+            cid = capi.comm_unique_id()
+
+    def outer_barrier():
+        if dist is not None and loopback_ranks == 0:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ranks_here = list(range(G)) if loopback_ranks > 0 else [rank]
+    results = split_rank_numbers(args, capi, torch, local_rank, G, ranks_here, cid, steps, warmup, outer_barrier)
+    mine = results[ranks_here[0]]
     elapsed = mine["elapsed"]
     if dist is not None and loopback_ranks == 0:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -369,6 +380,13 @@ def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, w
         elapsed = float(t.item())
     if rank != 0:
         return None
+    return split_line(args, world, G, mine, elapsed, steps, warmup, loopback_ranks)
+
+
+def split_line(args, world, G, mine, elapsed, steps, warmup, loopback_ranks):
+    """The bench line of a split measurement from one rank's raw numbers and the slowest rank's time."""
+    W, D = args.split_walkers, 64
+    steps_per = SPLIT_STEPS_PER
     n_steps = steps_per * steps
     total = float(W) * n_steps
     launches, gpu_ms = mine["launches"], mine["gpu_ms"]
@@ -420,6 +438,46 @@ def split_measurement(args, rank, local_rank, world, dist, torch, capi, steps, w
     }
 
 
+def split_leg_in_children(args, rank, local_rank, world, dist, torch, capi, steps, warmup):
+    """The C5 leg of a multi-rank run, every rank of it in a CHILD process of the bench rank that owns the GPU: a crash or a hang
+    of code that has never met RCCL between GPUs before then costs this secondary entry, not the headline
+    the parent has already measured.  The parents hand the communicator id down, wait (bounded), collect the children's raw
+    numbers, agree on success and on the slowest rank's time; rank 0 assembles the line."""
+    import subprocess
+    with _StdoutToStderr():
+        box = [capi.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+    cid = box[0]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "split", "--child-rank", str(rank), "--child-world", str(world),
+           "--comm-id-hex", bytes(cid).hex(), "--child-device", str(local_rank), "--steps", str(steps), "--warmup", str(warmup),
+           "--split-walkers", str(args.split_walkers), "--no-live-counters"]
+    mine, why = None, ""
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = child.communicate(timeout=max(5.0, args.split_leg_seconds - 5.0))
+        if child.returncode == 0:
+            lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+            mine = json.loads(lines[-1]) if lines else None
+            why = "" if mine else "the child printed no numbers"
+        else:
+            why = "the child of rank %d ended with code %d: %s" % (rank, child.returncode, err.strip()[-300:])
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.communicate()
+        why = "the child of rank %d did not finish in time" % rank
+    ok = torch.tensor([1.0 if mine else 0.0, mine["elapsed"] if mine else 0.0], dtype=torch.float64,
+                      device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    oks = [torch.zeros_like(ok) for _ in range(world)]
+    dist.all_gather(oks, ok)
+    if not all(float(o[0]) > 0 for o in oks):
+        return {"workload": "C5 split over the ranks", "error": why or "another rank's child failed"} if rank == 0 else None
+    if rank != 0:
+        return None
+    elapsed = max(float(o[1]) for o in oks)
+    return split_line(args, world, world, mine, elapsed, steps, warmup, 0)
+
+
 class _Nothing:
     def __enter__(self):
         return self
@@ -468,6 +526,12 @@ def main():
     ap.add_argument("--loopback-ranks", type=int, default=0,
                     help="--mode split on ONE GPU: that many ranks as threads of this process, exchanging through the test-only loop-back "
                          "collective library (tests/cpp/loopback_ccl.hip) -- a rehearsal of the world > 1 code path")
+    ap.add_argument("--child-rank", type=int, default=-1,
+                    help="internal (--mode split): this process is one rank of --child-world ranks of the split measurement, started by "
+                         "a rank of a multi-rank run; it prints its raw numbers as one JSON object")
+    ap.add_argument("--child-world", type=int, default=0)
+    ap.add_argument("--comm-id-hex", default="")
+    ap.add_argument("--child-device", type=int, default=0)
     ap.add_argument("--no-split-leg", action="store_true", help="several ranks: skip the bounded C5 (split ensemble) measurement behind the chains")
     ap.add_argument("--split-leg-seconds", type=float, default=45.0, help="several ranks: time limit of that measurement")
     ap.add_argument("--calc", default="dense", choices=["dense", "iso", "rosenbrock"],
@@ -481,6 +545,18 @@ def main():
         if not os.path.exists(LOOPBACK_LIB):
             raise SystemExit("%s is missing: python -m pytest tests/test_split_loopback.py -k exports builds it" % LOOPBACK_LIB)
         os.environ["MCMCPP_HIP_RCCL_LIB"] = LOOPBACK_LIB
+
+    if args.child_rank >= 0:
+        # One rank of a split measurement in a process of its own (see the several-ranks branch below): no process group --
+        # the communicator id comes from the parent, the library's collectives keep the ranks in lockstep.
+        import torch
+        torch.cuda.set_device(args.child_device)
+        from mcmcpp_amd import capi
+        args.cpu_affinity = "inherited from the parent rank"
+        res = split_rank_numbers(args, capi, torch, args.child_device, args.child_world, [args.child_rank], bytes.fromhex(args.comm_id_hex),
+                                 args.steps, args.warmup, torch.cuda.synchronize)
+        print(json.dumps(res[args.child_rank]), flush=True)
+        return
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -687,21 +763,24 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             loop = world if os.environ.get("MCMCPP_BENCH_SPLIT_LEG") == "loopback" else 0
-            if loop and rank != 0:
-                split = None  # (rehearsal: rank 0 alone steps all ranks as threads through the loop-back library)
+            if loop:
+                # rehearsal: rank 0 alone steps all ranks as threads through the loop-back library
+                split = split_measurement(args, rank, local_rank, world, dist, torch, capi, steps=10, warmup=2, loopback_ranks=loop) if rank == 0 else None
+                if dist is not None:
+                    dist.barrier()
             else:
-                split = split_measurement(args, rank, local_rank, world, dist, torch, capi, steps=10, warmup=2, loopback_ranks=loop)
-            if loop and dist is not None:
-                dist.barrier()
+                split = split_leg_in_children(args, rank, local_rank, world, dist, torch, capi, steps=10, warmup=2)
+            broke_here = False
         except Exception as e:  # noqa: BLE001 -- the headline must not be lost to the secondary measurement
             split = {"workload": "C5 split over the ranks", "error": "%s: %s" % (type(e).__name__, e)}
+            broke_here = True
         done.set()
         if rank == 0 and split is not None:
             split["workload"] = split.get("config", {}).get("workload", split.get("workload"))
             line.setdefault("secondary", []).append(split)
-        if split is not None and "error" in split:
-            # (the other ranks may be stuck in a collective this rank never joined: their watchdogs end them; a tidy
-            #  shutdown of the process group would wait for them)
+        if broke_here:
+            # (an exception in THIS rank's part of the leg: the other ranks may be waiting in a collective this rank never
+            #  joined -- their watchdogs end them; a tidy shutdown of the process group would wait for them)
             if rank == 0:
                 print(json.dumps(line), flush=True)
             sys.stdout.flush()
