@@ -56,18 +56,23 @@ __global__ void __launch_bounds__(256) exchange_sync_seen_kernel(const uint32_t*
 }
 
 // A wavefront looks at kPackWalkersPerWave walkers of the slice (colours [color0, color0 + colors)), one per lane of its
-// first lanes, reserves slots for those that moved with one atomic, and copies their rows with all 64 lanes -- few
-// walkers per wavefront on purpose: the rows of a wavefront go one after the other (each a dependent load -> store), so
-// the launch is as long as the busiest wavefront's list (16 384 walkers at 16 % moved: 64 per wavefront 8.8 us, 16 per
-// wavefront about a third of that).  The block's count must be zero on entry (the scatter kernel of the previous
-// exchange, or the host at the start of a chunk, sees to that).
+// first lanes, and copies the rows of those that moved with all 64 lanes -- few walkers per wavefront on purpose: the rows
+// of a wavefront go one after the other (each a dependent load -> store), so the launch is as long as the busiest
+// wavefront's list.  Slots are reserved per WORKGROUP of 16 wavefronts (wave counts through LDS, one atomic on the block's
+// count, a prefix over the wavefronts): one atomic per wavefront on the same address costs ~12 ns each -- 1 024 of them
+// made this launch 17 us at C5's slice size, 64 make it 3.  The block's count must be zero on entry (the scatter kernel
+// of the previous exchange, or the host at the start of a chunk, sees to that).
 constexpr int kPackWalkersPerWave = 16;
+constexpr int kPackWavesPerBlock = 16;
 template <class T>
-__global__ void __launch_bounds__(256) exchange_pack_kernel(const T* pos, const T* logp, const uint32_t* n_accept, uint32_t* seen, char* block, uint32_t cap,
-                                                            int n, int dims, int shard_begin, int shard_count, int color0, int colors)
+__global__ void __launch_bounds__(64 * kPackWavesPerBlock) exchange_pack_kernel(const T* pos, const T* logp, const uint32_t* n_accept, uint32_t* seen, char* block,
+                                                                                   uint32_t cap, int n, int dims, int shard_begin, int shard_count, int color0, int colors)
 {
-    const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    __shared__ uint32_t wave_count[kPackWavesPerBlock];
+    __shared__ uint32_t block_base;
+    __shared__ int moved_walker[kPackWavesPerBlock][kPackWalkersPerWave];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int wave = (int)blockIdx.x * kPackWavesPerBlock + wib;
     const int i = wave * kPackWalkersPerWave + lane;
     const bool in_range = lane < kPackWalkersPerWave && i < colors * shard_count;
     const int w = in_range ? (color0 + i / shard_count) * n + shard_begin + i % shard_count : 0;
@@ -79,11 +84,18 @@ __global__ void __launch_bounds__(256) exchange_pack_kernel(const T* pos, const 
         if (moved) seen[w] = now;
     }
     const unsigned long long ballot = __ballot(moved);
+    if (lane == 0) wave_count[wib] = (uint32_t)__popcll(ballot);
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t total = 0;
+        for (int k = 0; k < kPackWavesPerBlock; ++k) total += wave_count[k];
+        block_base = total ? atomicAdd(&reinterpret_cast<XBlockHeader*>(block)->count, total) : 0u;
+    }
+    __syncthreads();
     if (ballot == 0) return;
-    XBlockHeader* hdr = reinterpret_cast<XBlockHeader*>(block);
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&hdr->count, (uint32_t)__popcll(ballot));
-    base = __shfl(base, 0, 64);
+    uint32_t base = block_base;
+    for (int k = 0; k < wib; ++k) base += wave_count[k];
     uint32_t* idx = reinterpret_cast<uint32_t*>(block + xblock_idx_offset());
     T* blogp = reinterpret_cast<T*>(block + xblock_logp_offset<T>(cap));
     T* brows = reinterpret_cast<T*>(block + xblock_rows_offset<T>(cap));
@@ -93,28 +105,31 @@ __global__ void __launch_bounds__(256) exchange_pack_kernel(const T* pos, const 
         idx[my_slot] = (uint32_t)w;
         blogp[my_slot] = logp[w];
     }
-    // the rows: the wavefront walks its moved walkers, 64 lanes share one row
+    // the rows: the wavefront's moved walkers listed through LDS (rank inside the wavefront -> walker), then copied
+    // 64 / pieces rows at a time (a 512-byte row is 32 pieces of 16 bytes: two rows per round), all loads of a round in flight
+    const uint32_t mine = (uint32_t)__popcll(ballot);
+    if (moved) moved_walker[wib][my_slot - base] = w;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const bool vec = ((size_t)dims * sizeof(T)) % 16 == 0;
-    unsigned long long left = ballot;
-    uint32_t slot = base;
-    while (left)
+    const int pieces = vec ? (int)((size_t)dims * sizeof(T) / 16) : dims;
+    int lpr = 1;  // lanes per row: a power of two, at most 64
+    while (lpr < pieces && lpr < 64) lpr <<= 1;
+    const int rows_per_round = 64 / lpr, sub = lane % lpr, rr = lane / lpr;
+    for (uint32_t r0 = 0; r0 < mine; r0 += (uint32_t)rows_per_round)
     {
-        const int src_lane = __ffsll((long long)left) - 1;
-        left &= left - 1;
-        const int sw = __shfl(w, src_lane, 64);
-        if (slot < cap)
+        const uint32_t r = r0 + (uint32_t)rr;
+        if (r >= mine || base + r >= cap) continue;
+        const int sw = moved_walker[wib][r];
+        if (vec)
         {
-            if (vec)
-            {
-                const int pieces = (int)((size_t)dims * sizeof(T) / 16);
-                const uint4* s = reinterpret_cast<const uint4*>(pos + (size_t)sw * dims);
-                uint4* d = reinterpret_cast<uint4*>(brows + (size_t)slot * dims);
-                for (int k = lane; k < pieces; k += 64) d[k] = s[k];
-            }
-            else
-                for (int k = lane; k < dims; k += 64) brows[(size_t)slot * dims + k] = pos[(size_t)sw * dims + k];
+            const uint4* sp = reinterpret_cast<const uint4*>(pos + (size_t)sw * dims);
+            uint4* dp = reinterpret_cast<uint4*>(brows + (size_t)(base + r) * dims);
+            for (int k = sub; k < pieces; k += lpr) dp[k] = sp[k];
         }
-        ++slot;
+        else
+            for (int k = sub; k < dims; k += lpr) brows[(size_t)(base + r) * dims + k] = pos[(size_t)sw * dims + k];
     }
 }
 

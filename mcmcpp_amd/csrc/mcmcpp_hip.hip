@@ -934,7 +934,7 @@ public:
         const size_t bb = xblock_bytes<T>(cap, D);
         char* own = d_xblocks + bb * (size_t)cfg.comm_rank;
         const int pack_waves = (colors * shard_count + kPackWalkersPerWave - 1) / kPackWalkersPerWave;
-        hipLaunchKernelGGL(exchange_pack_kernel<T>, dim3((unsigned)((pack_waves + 3) / 4)), dim3(256), 0, stream, (const T*)cur_pos, (const T*)cur_logp,
+        hipLaunchKernelGGL(exchange_pack_kernel<T>, dim3((unsigned)((pack_waves + kPackWavesPerBlock - 1) / kPackWavesPerBlock)), dim3(64 * kPackWavesPerBlock), 0, stream, (const T*)cur_pos, (const T*)cur_logp,
                            (const uint32_t*)d_nacc, d_seen, own, cap, n, D, shard_begin, shard_count, color0, colors);
         HIP_TRY(hipGetLastError());
         NCCL_TRY(rccl->AllGather(own, d_xblocks, bb, ncclInt8, comm, stream));
