@@ -1,12 +1,9 @@
 cd $GRAFT_REPO_ROOT
-python tools/time_config.py 16384 32 dense f64 2000 8
-MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS=100000000 python tools/time_config.py 16384 32 dense f64 2000 8
-python tools/time_config.py 65536 32 dense f64 500
-MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS=100000000 python tools/time_config.py 65536 32 dense f64 500
-python tools/time_config.py 131072 32 dense f64 500
-MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS=100000000 python tools/time_config.py 131072 32 dense f64 500
-python tools/time_config.py 262144 32 dense f64 200
-python tools/time_config.py 32768 32 dense f64 1000
-MCMCPP_HIP_FULL_STEP=0 python tools/time_config.py 32768 32 dense f64 1000
-MCMCPP_HIP_FULL_STEP=0 python tools/time_config.py 16384 32 dense f64 2000
-python tools/time_config.py 16384 32 dense f64 2000
+for dw in 1 0; do
+ echo "== MCMCPP_HIP_MC_DRAW_WAVES=$dw"
+ MCMCPP_HIP_MC_DRAW_WAVES=$dw python tools/time_config.py 16384 32 dense f64 2000 8
+ MCMCPP_HIP_MC_DRAW_WAVES=$dw python tools/time_config.py 65536 32 dense f64 500
+ MCMCPP_HIP_MC_DRAW_WAVES=$dw python tools/time_config.py 131072 32 dense f64 500
+ MCMCPP_HIP_MC_DRAW_WAVES=$dw python tools/time_config.py 262144 32 dense f64 200
+ MCMCPP_HIP_MC_DRAW_WAVES=$dw python tools/time_config.py 131072 32 dense f32 500
+done
