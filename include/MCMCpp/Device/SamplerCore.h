@@ -79,6 +79,15 @@ public:
         }
         // One ensemble split over G devices: one handle per device, all ranks of one RCCL communicator.  The communicator's
         // rendezvous blocks until every rank has joined, so the handles are created concurrently.
+        {
+            // Honest about its status: the exchange logic of this path is validated (several ranks on one GPU through a
+            // loop-back collective library), RCCL's transport between DIFFERENT GPUs has carried it with one rank only.
+            bool distinct = false;
+            for (int r = 1; r < G; ++r) distinct = distinct || where.device(r) != where.device(0);
+            if (distinct && std::getenv("MCMCPP_QUIET") == nullptr)
+                std::fprintf(stderr, "MCMCpp (MI355X): one ensemble split over %d GPUs -- note: this path has not yet run on multi-GPU hardware "
+                                     "(DESIGN.md section 5); results are checkable against a single-GPU run, which they must equal bit for bit\n", G);
+        }
         unsigned char commId[MCMCPP_HIP_COMM_ID_BYTES];
         HipHandle::checkCreate("mcmcpp_hip_comm_unique_id", mcmcpp_hip_comm_unique_id(commId));
         std::vector<std::thread> joiners;
