@@ -868,12 +868,13 @@ public:
         const int64_t total = n_saved * (int64_t)interval;
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
         // stored steps: device -> pinned staging on the launch stream, handed to the caller a staging buffer at a time
-        int64_t stage_slots = 0;
+        // (the same number on every rank, whether it stores or not: the chunks of a run end where the staging buffer of
+        //  the ranks that do store is full, and every rank must cut its run into the same chunks)
+        int64_t stage_slots = (int64_t)(((size_t)256 << 20) / step_bytes);
+        if (stage_slots < 1) stage_slots = 1;
+        if (stage_slots > n_saved) stage_slots = n_saved;
         if (chain_out && total > 0)
         {
-            stage_slots = (int64_t)(((size_t)256 << 20) / step_bytes);
-            if (stage_slots < 1) stage_slots = 1;
-            if (stage_slots > n_saved) stage_slots = n_saved;
             if (step_bytes * (size_t)stage_slots > split_stage_capacity)
             {
                 HIP_TRY(hipStreamSynchronize(stream));
@@ -889,7 +890,10 @@ public:
             }
         }
         *stage_slots_out = stage_slots;
-        const int rc = ensure_run_buffers(accepted_per_step ? (size_t)total : 0, 0, 0);
+        // (the per-step accepted counts are always kept on the device and all-reduced at the end of a split run, whether this
+        //  rank's caller wants them or not: a collective must not depend on one rank's arguments)
+        (void)accepted_per_step;
+        const int rc = ensure_run_buffers(total > 0 ? (size_t)total : 0, 0, 0);
         if (rc) return rc;
         if (ev_x.empty())
         {
@@ -902,17 +906,20 @@ public:
     // Every rank learns the worst status among the ranks (and that all were asked for the same number of steps) before any
     // of them launches or exchanges anything: a rank that failed its preparation would otherwise leave the others waiting
     // in their first all-gather for good.  One small all-reduce and one stream synchronisation per run.
-    int agree_on_status(int local_rc, int64_t total)
+    int agree_on_status(int local_rc, int64_t total, int32_t interval, bool stores, bool* any_rank_stores)
     {
         uint64_t* hs = reinterpret_cast<uint64_t*>(h_pinned);  // [0, 64): words out, [64, 128): words back
         hs[0] = (uint64_t)local_rc;
         hs[1] = (uint64_t)total;
         hs[2] = ~(uint64_t)total;
+        hs[3] = (uint64_t)(uint32_t)interval;
+        hs[4] = ~(uint64_t)(uint32_t)interval;
+        hs[5] = stores ? 1u : 0u;  // (stored steps are handed out a staging buffer at a time: where the chunks of the run end)
         const std::string mine = error;
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipMemcpyAsync(d_status, hs, 3 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-        NCCL_TRY(rccl->AllReduce(d_status, d_status, 3, ncclUint64, ncclMax, comm, stream));
-        HIP_TRY(hipMemcpyAsync(hs + 8, d_status, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(d_status, hs, 6 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+        NCCL_TRY(rccl->AllReduce(d_status, d_status, 6, ncclUint64, ncclMax, comm, stream));
+        HIP_TRY(hipMemcpyAsync(hs + 8, d_status, 6 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         if (local_rc != MCMCPP_HIP_OK)
         {
@@ -920,7 +927,9 @@ public:
             return local_rc;
         }
         if (hs[8] != 0) return fail((int)hs[8], "run: the preparation of another rank of the split ensemble failed (code %d); nothing was launched", (int)hs[8]);
-        if (hs[9] != ~hs[10]) return fail(MCMCPP_HIP_E_ARG, "run: the ranks of the split ensemble were asked for different numbers of steps; nothing was launched");
+        if (hs[9] != ~hs[10] || hs[11] != ~hs[12])
+            return fail(MCMCPP_HIP_E_ARG, "run: the ranks of the split ensemble were asked for different numbers of steps or intervals; nothing was launched");
+        *any_rank_stores = hs[13] != 0;
         return MCMCPP_HIP_OK;
     }
 
@@ -976,12 +985,13 @@ public:
         int64_t stage_slots = 0;
         const int prep = prepare_split(n_saved, interval, chain_out, accepted_per_step, &stage_slots);
         const int64_t total = (n_saved > 0 && interval > 0) ? n_saved * (int64_t)interval : 0;
-        int rc = agree_on_status(prep, total);
+        bool any_rank_stores = false;
+        int rc = agree_on_status(prep, total, interval, chain_out != nullptr, &any_rank_stores);
         if (rc) return rc;
         if (total == 0) return MCMCPP_HIP_OK;
         const size_t step_bytes = sizeof(T) * (size_t)W * D;
         constexpr int kMaxSamples = kMaxExchangeSamples;
-        if (accepted_per_step) HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
+        HIP_TRY(hipMemsetAsync(d_acc, 0, sizeof(uint32_t) * (size_t)total, stream));
         run_touched_device = true;
         rc = write_ctl(0);
         if (rc) return rc;
@@ -990,7 +1000,7 @@ public:
         {
             RunInfo* ri = reinterpret_cast<RunInfo*>((char*)h_pinned + 256);
             ri->chain = nullptr;  // (stored steps are copied from the replica after the exchange)
-            ri->accepted_per_step = accepted_per_step ? d_acc : nullptr;
+            ri->accepted_per_step = d_acc;
             ri->interval = interval;
             ri->chain_slot_base = 0;
             ri->stage = nullptr;
@@ -1049,7 +1059,7 @@ public:
                 const int64_t want = learning ? 16 : knobs.comm_compact_chunk;
                 if (len > want) len = want;
             }
-            if (chain_out)
+            if (any_rank_stores)
             {
                 const int64_t fits = (s0 / interval + stage_slots) * (int64_t)interval - s0;  // steps until the staging buffer is full
                 if (len > fits) len = fits;
@@ -1129,7 +1139,7 @@ public:
             const bool more = s0 + len < total;
             if (compact)
             {
-                XStats* hx = reinterpret_cast<XStats*>((char*)h_pinned + 96);
+                XStats* hx = reinterpret_cast<XStats*>((char*)h_pinned + 112);  // (behind the status words agree_on_status reads back)
                 HIP_TRY(hipMemcpyAsync(hx, d_xstats, sizeof(XStats), hipMemcpyDeviceToHost, stream));
                 HIP_TRY(hipStreamSynchronize(stream));
                 if (hx->overflow)
@@ -1201,7 +1211,7 @@ public:
                 NCCL_TRY(rccl->AllGather(d_logp + (size_t)c * n + shard_begin, d_logp + (size_t)c * n, (size_t)shard_count, RcclType<T>::value, comm, stream));
             NCCL_TRY(rccl->AllGather(d_nacc + (size_t)c * n + shard_begin, d_nacc + (size_t)c * n, (size_t)shard_count, ncclUint32, comm, stream));
         }
-        if (accepted_per_step) NCCL_TRY(rccl->AllReduce(d_acc, d_acc, (size_t)total, ncclUint32, ncclSum, comm, stream));
+        NCCL_TRY(rccl->AllReduce(d_acc, d_acc, (size_t)total, ncclUint32, ncclSum, comm, stream));
         NCCL_TRY(rccl->GroupEnd());
         HIP_TRY(hipStreamSynchronize(stream));
         {
