@@ -196,6 +196,10 @@ case("c5_131072x64_G4_rank0_stores_more_than_a_staging_buffer")(lambda: run_rank
     4, 131072, 64, po.CALC_ISO_GAUSSIAN, scheme="step", runs=((7, 1), (3, 2)), chain_on="rank0", seed=0, oracle_threads=8))
 case("iso32768x64_G2_rank0_stores_half_scheme")(lambda: run_ranks(
     2, 32768, 64, po.CALC_ISO_GAUSSIAN, scheme="half", runs=((20, 1),), chain_on="rank0", env={"MCMCPP_HIP_COMM_COMPACT_CHUNK": "6"}))
+# slices that fill neither a wavefront nor a pack workgroup, rows that are not a multiple of 16 bytes
+for _scheme in ("step", "half"):
+    case("rosen296x3_G2_%s" % _scheme)(lambda scheme=_scheme: run_ranks(2, 296, 3, po.CALC_ROSENBROCK, scheme=scheme, runs=((25, 2), (7, 1))))
+    case("iso340x5_f32_G5_%s" % _scheme)(lambda scheme=_scheme: run_ranks(5, 340, 5, po.CALC_ISO_GAUSSIAN, dtype=capi.F32, scheme=scheme, runs=((30, 1),)))
 case("one_rank_fails_before_the_first_launch")(lambda: run_ranks(4, 4096, 32, po.CALC_ISO_GAUSSIAN, runs=((2, 2),), bad_rank=2))
 # BASELINE config 5 at full size, eight ranks (8 192 walkers of each colour per rank): one exchange per ensemble step, then
 # the reference's scheme (one per half-step)
