@@ -34,7 +34,11 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 template <class T, class Calc, int EPL, int LPW, int P>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
+#if MCMCPP_EXP_LEAN
+    const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS + 1024) * sizeof(T);
+#else
     const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS) * sizeof(T);
+#endif
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);

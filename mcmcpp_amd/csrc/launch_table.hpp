@@ -59,7 +59,7 @@ void launch_fill_draws(const HalfStepArgs<float>& a, U128 base, const U128* red_
 void launch_fill_draws_batch(const HalfStepArgs<double>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<double>* out, int steps, hipStream_t stream);
 void launch_fill_draws_batch(const HalfStepArgs<float>& a, const StepCtl* ctl, const Affine128* step_jump, DrawRec<float>* out, int steps, hipStream_t stream);
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
-                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains = 1);
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains = 1, StepCtl* ctl_keep = nullptr);
 
 // one definition per (element type, calculator), each in its own translation unit
 const LaunchTable<double>* launch_table_f64_iso();

@@ -93,6 +93,7 @@ struct Knobs
     long trickle;                 // MCMCPP_HIP_TRICKLE                  1: stored steps forwarded to pinned memory by the launches (1)
     long no_draw_wave;            // MCMCPP_HIP_NO_DRAW_WAVE             1: no extra draw wavefronts (0)
     long batch_draws;             // MCMCPP_HIP_BATCH_DRAWS              ensemble steps whose draw records one launch makes ahead of the matrix-core full-step launches; 0: the launches make them themselves; -1: as many as a graph replays (-1)
+    long fill_branch;             // MCMCPP_HIP_FILL_BRANCH              > 0: the records of the NEXT graph replay are made beside this replay's step launches, in that many pieces on a parallel branch of the graph (0: one launch in line at the head of each replay)
     long copy_stream;             // MCMCPP_HIP_COPY_STREAM              1: chain downloads on a second stream (0)
     long pinned_direct;           // MCMCPP_HIP_PINNED_DIRECT            1: stored steps forwarded straight into a pinned chain_out (1)
     long comm_full_step;          // MCMCPP_HIP_COMM_FULL_STEP           split ensembles: 1 = one exchange per ensemble step (1), 0 = one per half-step
@@ -117,6 +118,7 @@ struct Knobs
         k.trickle = env_long("MCMCPP_HIP_TRICKLE", 1);
         k.no_draw_wave = env_long("MCMCPP_HIP_NO_DRAW_WAVE", 0);
         k.batch_draws = env_long("MCMCPP_HIP_BATCH_DRAWS", -1);
+        k.fill_branch = env_long("MCMCPP_HIP_FILL_BRANCH", 0);
         k.copy_stream = env_long("MCMCPP_HIP_COPY_STREAM", 0);
         k.pinned_direct = env_long("MCMCPP_HIP_PINNED_DIRECT", 1);
         k.comm_full_step = env_long("MCMCPP_HIP_COMM_FULL_STEP", 1);
@@ -210,10 +212,10 @@ void launch_fill_draws_batch(const HalfStepArgs<float>& a, const StepCtl* ctl, c
     hipLaunchKernelGGL(fill_draws_batch_kernel<float>, dim3(grid, (unsigned)(2 * steps)), dim3(192), 0, stream, a, ctl, step_jump, out);
 }
 void launch_accepted_reduce(const uint32_t* partials, int partial_slots, int partial_waves, int count,
-                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains)
+                            const StepCtl* ctl_after, const RunInfo* run, hipStream_t stream, int chains, StepCtl* ctl_keep)
 {
     hipLaunchKernelGGL(accepted_reduce_kernel, dim3((unsigned)count, (unsigned)(chains > 1 ? chains : 1)), dim3(256), 0, stream, partials, partial_slots,
-                       partial_waves, count, ctl_after, run);
+                       partial_waves, count, ctl_after, run, ctl_keep);
 }
 }  // namespace mcmcpp
 
@@ -539,8 +541,20 @@ public:
             batch_draws = (int)(want > 512 ? 512 : want);
             HIP_TRY(hipMalloc(&d_draws_batch, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));
             HIP_TRY(hipMemset(d_draws_batch, 0, sizeof(DrawRec<T>) * (size_t)batch_draws * 2 * (size_t)n));  // (partner indices a kernel may follow)
-            std::vector<Affine128> sj((size_t)batch_draws);
-            for (int j = 0; j < batch_draws; ++j) sj[(size_t)j] = pcg_jump(inc, (unsigned __int128)6 * (unsigned)n * (unsigned)j);
+            // Records of the NEXT replay made beside this replay's launches (fill_pieces > 0): piece k, forked off the launch
+            // sequence behind the last step that read its record sets, refills them for the same steps of the next replay
+            // from the control record the previous replay left in d_ctl_keep (step_jump[batch_draws + j]).
+            if (knobs.fill_branch > 0 && batch_draws == graph_steps && batch_draws >= 2)
+            {
+                fill_pieces = (int)(knobs.fill_branch < batch_draws ? knobs.fill_branch : batch_draws);
+                HIP_TRY(hipStreamCreateWithFlags(&fill_stream, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&ev_fill_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&ev_fill_join, hipEventDisableTiming));
+                HIP_TRY(hipMalloc(&d_ctl_keep, sizeof(StepCtl)));
+                HIP_TRY(hipMemset(d_ctl_keep, 0, sizeof(StepCtl)));
+            }
+            std::vector<Affine128> sj((size_t)batch_draws * (fill_pieces > 0 ? 2 : 1));
+            for (size_t j = 0; j < sj.size(); ++j) sj[j] = pcg_jump(inc, (unsigned __int128)6 * (unsigned)n * (unsigned __int128)j);
             HIP_TRY(hipMalloc(&d_step_jump, sizeof(Affine128) * sj.size()));
             HIP_TRY(hipMemcpy(d_step_jump, sj.data(), sizeof(Affine128) * sj.size(), hipMemcpyHostToDevice));
         }
@@ -586,6 +600,7 @@ public:
         half_steps = 0;
         steps_since_reset = 0;
         records_valid = false;
+        records_ahead_of = kNoStep;
         int rc = write_ctl(0);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
@@ -633,6 +648,7 @@ public:
         (void)hipGetLastError();
         have_state = false;
         records_valid = false;
+        records_ahead_of = kNoStep;
         error = keep + " (the walker state on the device is no longer consistent: call set_state again)";
     }
 
@@ -1392,6 +1408,7 @@ public:
         HIP_TRY(hipSetDevice(device));
         half_steps = 2 * steps_done;
         records_valid = false;
+        records_ahead_of = kNoStep;
         return write_ctl(0);  // repositions the stream and re-primes the draw records of the next two half-steps
     }
 
@@ -1649,6 +1666,7 @@ private:
             c->save_phase = (uint32_t)(step_in_run % (uint64_t)interval);
             c->partial_slot = (uint32_t)(step_in_run % (uint64_t)partial_slots);
             HIP_TRY(hipMemcpyAsync(ctl_of(k) + (half_steps & 1), c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
+            if (d_ctl_keep) HIP_TRY(hipMemcpyAsync(d_ctl_keep, c, sizeof(StepCtl), hipMemcpyHostToDevice, stream));
             if (refill)
             {
                 const int parity = (int)((half_steps >> 1) & 1);  // the buffer the coming ensemble step reads
@@ -1708,34 +1726,63 @@ private:
         launch_fill_draws_batch(a, d_ctl + pos_parity, d_step_jump, d_draws_batch, count, stream);
     }
 
-    // `steps` ensemble steps from record-buffer parity start_parity / position-buffer parity pos_parity on
-    void enqueue_step_sequence(int steps, int start_parity, int pos_parity)
+    // record sets [first, first + count) for the same steps of the NEXT replay, on the parallel branch (stream capture:
+    // the fork is the event, the join comes before the accepted-count reduction)
+    int fork_fill_of_next_replay(int first, int count)
     {
+        HalfStepArgs<T> a = args_red;
+        a.draws = d_draws;
+        HIP_TRY(hipEventRecord(ev_fill_fork, stream));
+        HIP_TRY(hipStreamWaitEvent(fill_stream, ev_fill_fork, 0));
+        launch_fill_draws_batch(a, d_ctl_keep, d_step_jump + batch_draws + first, d_draws_batch + (size_t)first * 2 * (size_t)n, count, fill_stream);
+        return MCMCPP_HIP_OK;
+    }
+
+    // `steps` ensemble steps from record-buffer parity start_parity / position-buffer parity pos_parity on
+    // records_ahead: the batch records of these steps are in place (the replay before made them on its branch);
+    // fill_next: make the next replay's on a branch of this one
+    int enqueue_step_sequence(int steps, int start_parity, int pos_parity, bool records_ahead = false, bool fill_next = false)
+    {
+        int piece_first = 0, piece = 0;
         for (int s = 0; s < steps; ++s)
         {
             if (batch_draws > 0)
             {
-                if (s % batch_draws == 0) fill_batch((pos_parity + s) & 1, steps - s < batch_draws ? steps - s : batch_draws);
+                if (s % batch_draws == 0 && !(s == 0 && records_ahead)) fill_batch((pos_parity + s) & 1, steps - s < batch_draws ? steps - s : batch_draws);
                 enqueue_step(0, (pos_parity + s) & 1, s % batch_draws);
+                if (fill_next && (s + 1 == (int)(((int64_t)steps * (piece + 1)) / fill_pieces)))
+                {
+                    if (int rc = fork_fill_of_next_replay(piece_first, s + 1 - piece_first)) return rc;
+                    piece_first = s + 1;
+                    ++piece;
+                }
             }
             else
                 enqueue_step((start_parity + s) & 1, (pos_parity + s) & 1);
         }
+        if (fill_next)
+        {
+            HIP_TRY(hipEventRecord(ev_fill_join, fill_stream));
+            HIP_TRY(hipStreamWaitEvent(stream, ev_fill_join, 0));
+        }
+        return MCMCPP_HIP_OK;
     }
 
     // hipGraph of `steps` ensemble steps followed by the accepted-count reduction (cached per step count:
     // graph_steps for the bulk, one graph per distinct remainder)
     // (the record-buffer parity of every node is frozen into the graph, hence one graph per starting parity)
-    int graph_for(int steps, int start_parity, int pos_parity, hipGraphExec_t* out)
+    // (with records made a replay ahead: a replay of graph_steps steps always makes the next replay's on its branch, and
+    //  one graph per "the records of my own steps are in place already")
+    int graph_for(int steps, int start_parity, int pos_parity, hipGraphExec_t* out, bool records_ahead = false)
     {
-        const size_t key = (size_t)steps * 4 + (size_t)start_parity * 2 + (size_t)pos_parity;
+        const size_t key = ((size_t)steps * 2 + (records_ahead ? 1 : 0)) * 4 + (size_t)start_parity * 2 + (size_t)pos_parity;
         if (graph_cache.size() <= key) graph_cache.resize(key + 1, nullptr);
         if (!graph_cache[key])
         {
             hipGraph_t g = nullptr;
             HIP_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeRelaxed));
-            enqueue_step_sequence(steps, start_parity, pos_parity);
-            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream, K);
+            if (int rc = enqueue_step_sequence(steps, start_parity, pos_parity, records_ahead, fill_pieces > 0 && steps == graph_steps)) return rc;
+            launch_accepted_reduce(d_partials, partial_slots, partial_waves, steps, ctl_after(pos_parity + steps), d_run, stream, K, d_ctl_keep);
             HIP_TRY(hipStreamEndCapture(stream, &g));
             hipGraphExec_t ex = nullptr;
             HIP_TRY(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
@@ -1750,7 +1797,7 @@ private:
     {
         if (graph_steps < 1) return MCMCPP_HIP_OK;
         hipGraphExec_t ex;
-        return graph_for(graph_steps, (int)(enq_step & 1), 0, &ex);
+        return graph_for(graph_steps, (int)(enq_step & 1), 0, &ex, fill_pieces > 0 && records_ahead_of == enq_step);
     }
 
     // the control record the last launch of a step sequence leaves behind: the half-step pair always ends in [0],
@@ -1767,27 +1814,31 @@ private:
             hipGraphExec_t ex = nullptr;
             while (left >= graph_steps)
             {
-                int rc = graph_for(graph_steps, (int)(enq_step & 1), (int)(run_step & 1), &ex);
+                int rc = graph_for(graph_steps, (int)(enq_step & 1), (int)(run_step & 1), &ex, fill_pieces > 0 && records_ahead_of == enq_step);
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
                 left -= graph_steps;
                 enq_step += (uint64_t)graph_steps;
                 run_step += (uint64_t)graph_steps;
+                records_ahead_of = fill_pieces > 0 ? enq_step : kNoStep;
             }
             if (left > 0)
             {
-                int rc = graph_for((int)left, (int)(enq_step & 1), (int)(run_step & 1), &ex);  // one replay for the remainder
+                // one replay for the remainder (it may use records made ahead, it makes none: the record sets would no
+                // longer line up with the steps of a whole replay)
+                int rc = graph_for((int)left, (int)(enq_step & 1), (int)(run_step & 1), &ex, fill_pieces > 0 && records_ahead_of == enq_step);
                 if (rc) return rc;
                 HIP_TRY(hipGraphLaunch(ex, stream));
                 enq_step += (uint64_t)left;
                 run_step += (uint64_t)left;
+                records_ahead_of = kNoStep;
             }
         }
         else
         {
             for (; left > 0; --left)
             {
-                enqueue_step_sequence(1, (int)(enq_step & 1), (int)(run_step & 1));
+                (void)enqueue_step_sequence(1, (int)(enq_step & 1), (int)(run_step & 1));
                 launch_accepted_reduce(d_partials, partial_slots, partial_waves, 1, ctl_after((int64_t)run_step + 1), d_run, stream, K);
                 enq_step += 1;
                 run_step += 1;
@@ -1870,6 +1921,10 @@ private:
         if (d_acc) hipFree(d_acc);
         if (d_draws_batch) hipFree(d_draws_batch);
         if (d_step_jump) hipFree(d_step_jump);
+        if (d_ctl_keep) hipFree(d_ctl_keep);
+        if (fill_stream) hipStreamDestroy(fill_stream);
+        if (ev_fill_fork) hipEventDestroy(ev_fill_fork);
+        if (ev_fill_join) hipEventDestroy(ev_fill_join);
         for (int k = 0; k < 2; ++k)
         {
             if (d_chain[k]) hipFree(d_chain[k]);
@@ -1948,6 +2003,12 @@ private:
     DrawRec<T>* d_draws_batch = nullptr;  // [batch_draws][2][n]: records made ahead of the matrix-core full-step launches
     Affine128* d_step_jump = nullptr;     // [batch_draws]
     int batch_draws = 0;                  // 0: the step launches make their own next records
+    int fill_pieces = 0;                  // > 0: a whole replay makes the next replay's records on a parallel branch, in that many pieces
+    hipStream_t fill_stream = nullptr;    // (capture only: the branch)
+    hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;
+    StepCtl* d_ctl_keep = nullptr;        // the control record at the head of the coming replay (write_ctl, accepted_reduce_kernel)
+    static constexpr uint64_t kNoStep = ~0ULL;
+    uint64_t records_ahead_of = kNoStep;  // the ensemble step (since set_state) whose records sit in record set 0, made ahead by a branch
     static constexpr size_t kStampWords = 8 + 2 * 3 * 4096 + 8;
     unsigned long long* d_stamps = nullptr;  // diagnostic build only
     uint32_t* d_partials = nullptr;

@@ -1151,7 +1151,11 @@ __device__ __forceinline__ void mc_eval(const McB<T>& B, T* sx, int sub, int grp
 
 // P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
 template <class T, class Calc, int EPL, int LPW, int P, bool DW, bool MC = false>
+#if MCMCPP_EXP_LEAN_FORCE4
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)), (P == 4 && !DW && sizeof(T) == 8) ? 4 : 1)
+#else
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
+#endif
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const T* hot_matrix, const HalfStepArgs<T> rest)
 {
@@ -1283,7 +1287,16 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // the partner gather so that it does not compete with the records the gather waits for
     asm volatile("" ::: "memory");
     McB<T> matB;
+#if MCMCPP_EXP_LEAN
+    // experiment: P^T through an LDS copy the workgroup's wavefronts fill behind their gathers (a barrier before the tile)
+    T* sh_pt = reinterpret_cast<T*>(smem) + kWavesPerBlock * (kStageRows * XS);
+    typedef T V4 __attribute__((ext_vector_type(4)));
+    V4 mpiece;
+    if constexpr (!DW) mpiece = *reinterpret_cast<const V4*>(hot_matrix + 4 * threadIdx.x);
+    else mc_load_b(hot_matrix, sub, grp, matB);
+#else
     mc_load_b(hot_matrix, sub, grp, matB);
+#endif
     MCMCPP_STAMP(1);  // records landed, partner gather issued
 
     // ---- in its shadow: hand-over to the next launch, the walkers' next draws ------------------------------------------
@@ -1291,6 +1304,13 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // in the extra wavefront it would lengthen the last wavefront to finish: measured)
     if (blockIdx.x == 0 && threadIdx.x == 0)
         hand_over<T>(a, ctl, run, h_color, reinterpret_cast<StepCtl*>(reinterpret_cast<char*>(a.ctl_out) + (size_t)chain * kCtlChainStride));
+#if MCMCPP_EXP_LEAN
+    if constexpr (!DW)
+    {
+        *reinterpret_cast<V4*>(sh_pt + 4 * threadIdx.x) = mpiece;
+        __syncthreads();
+    }
+#endif
     if (!wave_active) return;
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
@@ -1300,11 +1320,13 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // Without a draw wavefront (16 walkers per wavefront) the walkers' next draws are made here, in the shadow of the
     // gather.  (Behind the update instead -- fewer registers live across the tile, one more wavefront per SIMD -- the
     // launch is 3 % shorter at 131 072 updates but 7 % longer at 65 536: profiles/r03_mc_probe_*.txt.)
+#if !MCMCPP_EXP_LEAN_NODRAW
     if constexpr (!DW)
     {
         if (lane < 3 * NW && first + slot_a < h_shard_count)
             compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
     }
+#endif
     MCMCPP_STAMP(2);  // next draws done
 
     // ---- proposals (StretchMove.h:105-108) -----------------------------------------------------------------------
@@ -1324,6 +1346,9 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
 
     // ---- Y = X * P^T on the matrix cores, products and the canonical tree ------------------------------------------
     T lp_new[P];
+#if MCMCPP_EXP_LEAN
+    if constexpr (!DW) mc_load_b(sh_pt, sub, grp, matB);
+#endif
     mc_eval<P>(matB, sh_x, sub, grp, h_dims, prop, lp_new);
     MCMCPP_STAMP(4);  // calculator done
 
@@ -1388,9 +1413,11 @@ __global__ void __launch_bounds__(256) mark_rows_moved_kernel(uint32_t* n_accept
 #ifdef MCMCPP_DEFINE_REDUCE_KERNEL  // one definition, in mcmcpp_hip.hip
 __global__ void __launch_bounds__(256)
 accepted_reduce_kernel(const uint32_t* partials, int partial_slots, int partial_waves, int count, const StepCtl* ctl_after,
-                       const RunInfo* run_ptr)
+                       const RunInfo* run_ptr, StepCtl* ctl_keep)
 {
     __shared__ unsigned sums[4];
+    // (one chain, records made a replay ahead: the control record at the head of the next replay, out of the step launches' way)
+    if (ctl_keep != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ctl_keep = *ctl_after;
     // (blockIdx.y: the chain, see ChainGeometry)
     partials += (size_t)blockIdx.y * (size_t)partial_slots * 2 * (size_t)partial_waves;
     ctl_after = reinterpret_cast<const StepCtl*>(reinterpret_cast<const char*>(ctl_after) + (size_t)blockIdx.y * kCtlChainStride);

@@ -227,6 +227,35 @@ def test_draw_records_made_ahead_in_batches_of_any_length(monkeypatch, batch):
     _assert_same_state(orc, hip)
 
 
+@pytest.mark.parametrize("pieces", ["1", "3", "8"])
+def test_draw_records_of_the_next_replay_made_on_a_branch_of_this_one(monkeypatch, pieces):
+    """MCMCPP_HIP_FILL_BRANCH = p: a whole graph replay makes the NEXT replay's draw records beside its own step launches, in
+    p pieces on a parallel branch of the graph (piece k forked off behind the last step that read its record sets).  Whole
+    replays, remainders that use records made ahead, remainders that make their own, runs that store steps and runs that do
+    not, a seek in between: the chain and the accepted counts are the oracle's."""
+    monkeypatch.setenv("MCMCPP_HIP_FILL_BRANCH", pieces)
+    monkeypatch.setenv("MCMCPP_HIP_GRAPH_STEPS", "8")
+    orc, hip = _oracle_and_hip(2048 + 6, 32, po.CALC_DENSE_GAUSSIAN, po.F64, seed=5, steps=0)
+    oc, oa = orc.run(104, interval=1, mode=po.MODE_COUNTER, threads=4)
+    at = 0
+    for steps, save in ((3, False), (27, False), (16, True), (8, False), (9, False), (17, True), (24, False)):
+        hc, ha = hip.run(steps, interval=1, save_chain=save)
+        np.testing.assert_array_equal(ha, oa[at:at + steps])
+        if save:
+            np.testing.assert_array_equal(hc, oc[at:at + steps])
+        at += steps
+    assert at == 104
+    _assert_same_state(orc, hip)
+    # back to step 40 with the walkers as they stand: records made ahead for another step must not be used
+    hip.seek(40)
+    orc.seek(40)
+    oc2, oa2 = orc.run(20, interval=1, mode=po.MODE_COUNTER, threads=4)
+    hc2, ha2 = hip.run(20, interval=1)
+    np.testing.assert_array_equal(hc2, oc2)
+    np.testing.assert_array_equal(ha2, oa2)
+    _assert_same_state(orc, hip)
+
+
 def test_checkpoint_and_resume_in_a_new_handle(step_path):
     """get_state + the number of steps done is a complete checkpoint: a fresh handle resumes the trajectory."""
     orc, hip = _oracle_and_hip(1024, 16, po.CALC_DENSE_GAUSSIAN, po.F64, seed=21, steps=0)
