@@ -31,25 +31,32 @@ void launch_half(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 #undef MCMCPP_LAUNCH_HALF
 }
 
-template <class T, class Calc, int EPL, int LPW, int P>
+template <class T, class Calc, int EPL, int LPW, int P, bool LATE = false>
 void launch_half_mfma(const HalfStepArgs<T>& a, unsigned grid, hipStream_t st)
 {
-#if MCMCPP_EXP_LEAN
+    // (staging rows of the workgroup's wavefronts, then the 32 x 32 matrix shared by workgroups without a draw wavefront)
     const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS + 1024) * sizeof(T);
-#else
-    const size_t lds = ((size_t)kWavesPerBlock * (sizeof(T) == 8 ? 4 * P : 16) * kMcXS) * sizeof(T);
-#endif
     const int chains = a.chains > 1 ? a.chains : 1;
     const uint32_t bits = HotBits::pack(a.dims, a.passes, a.color, a.vec_ok, a.n_is_pow2, a.use_ctl_save, a.draw_parity, a.draw_wave, a.task_jump != nullptr) |
                           ((uint32_t)(chains - 1) << 28);
 #define MCMCPP_LAUNCH_HALF_MC(DW, MC, THREADS)                                                                                                            \
-    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, DW, MC>), dim3(grid, chains), dim3(THREADS), lds, st, a.draws, a.pos, a.logp, a.n_accept, \
+    hipLaunchKernelGGL((stretch_half_step_mfma_kernel<T, Calc, EPL, LPW, P, DW, MC, (LATE && !(DW))>), dim3(grid, chains), dim3(THREADS), lds, st, a.draws, a.pos, a.logp, a.n_accept, \
                        a.n, bits, a.shard_begin, a.shard_count, a.ctl_in, a.calc_params_padded, a)
-    if (a.draw_wave && chains > 1)
-        MCMCPP_LAUNCH_HALF_MC(true, true, 64 * (kWavesPerBlock + 1));
-    else if (a.draw_wave)
-        MCMCPP_LAUNCH_HALF_MC(true, false, 64 * (kWavesPerBlock + 1));
-    else if (chains > 1)
+    // (wavefronts of 16 walkers make their next draws themselves: the host never asks for a draw wavefront there)
+    if constexpr (P < 4)
+    {
+        if (a.draw_wave && chains > 1)
+        {
+            MCMCPP_LAUNCH_HALF_MC(true, true, 64 * (kWavesPerBlock + 1));
+            return;
+        }
+        if (a.draw_wave)
+        {
+            MCMCPP_LAUNCH_HALF_MC(true, false, 64 * (kWavesPerBlock + 1));
+            return;
+        }
+    }
+    if (chains > 1)
         MCMCPP_LAUNCH_HALF_MC(false, true, 64 * kWavesPerBlock);
     else
         MCMCPP_LAUNCH_HALF_MC(false, false, 64 * kWavesPerBlock);
@@ -129,6 +136,7 @@ void put(LaunchTable<T>& t)
         //  fp32 walkers of 17..32 dimensions the slot is 8 lanes x 4 elements)
         t.half_step_mc[0][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, 2, 16, 2>;
         t.half_step_mc[1][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, 2, 16, 4>;
+        t.half_step_mc[2][LPWLOG][EPLSHIFT] = &launch_half_mfma<T, Calc, 2, 16, 4, true>;
         t.full_step_mc[LPWLOG][EPLSHIFT] = &launch_full_mfma<T, Calc, 2, 16>;
         t.de_update_mc[0][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, 2, 16, 2>;
         t.de_update_mc[1][LPWLOG][EPLSHIFT] = &launch_de_mfma<T, Calc, 2, 16, 4>;

@@ -14,7 +14,7 @@ namespace mcmcpp
 constexpr int kMaxEplShift = 4;
 constexpr int kLpwLevels = 7;  // LPW = 1,2,4,...,64
 
-constexpr uint32_t kLaunchTableAbi = 0x4D430017u;  // bumped whenever HalfStepArgs or the launcher signatures change
+constexpr uint32_t kLaunchTableAbi = 0x4D430018u;  // bumped whenever HalfStepArgs or the launcher signatures change
 
 template <class T>
 struct LaunchTable
@@ -28,7 +28,7 @@ struct LaunchTable
     HalfStepFn half_step[kLpwLevels][kMaxEplShift];
     CalcFn calc[kLpwLevels][kMaxEplShift];
     // matrix-core variants (nullptr where the calculator has none): need even D and exactly 2 ([0]) / 4 ([1]) passes
-    HalfStepFn half_step_mc[2][kLpwLevels][kMaxEplShift];
+    HalfStepFn half_step_mc[3][kLpwLevels][kMaxEplShift];  // [8 walkers per wavefront | 16 | 16 with the next draws behind the accept]
     // one launch per ensemble step (full_step_kernel.hpp); grid counts workgroups of 4 x (64/LPW) walkers per colour
     // (generic) or 32 per colour (matrix-core variant)
     HalfStepFn full_step[kLpwLevels][kMaxEplShift];

@@ -83,6 +83,7 @@ struct Knobs
     long waves_per_simd;          // MCMCPP_HIP_WAVES_PER_SIMD           wavefronts per SIMD to reach before a wavefront takes more walkers (2)
     long matrix_core_min_walkers; // MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS  smallest shard stepped by the matrix-core kernels (0; -1: never)
     long matrix_core_4pass;       // MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS from this many walkers per half on: 16 walkers per wavefront (32768)
+    long matrix_core_late;        // MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS    from this many updates per launch on: the 16-walker wavefronts make their next draws behind the accept, four to a SIMD (49152; -1: never)
     long full_step;               // MCMCPP_HIP_FULL_STEP                1: one launch per ensemble step for small ensembles (1)
     long full_step_max_walkers;   // MCMCPP_HIP_FULL_STEP_MAX_WALKERS    largest ensemble stepped that way (-1: 32768; 32767 where the matrix-core
                                   //                                     half-step kernel is the alternative)
@@ -109,6 +110,7 @@ struct Knobs
         k.waves_per_simd = env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
         k.matrix_core_min_walkers = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
         k.matrix_core_4pass = env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768);
+        k.matrix_core_late = env_long("MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS", 49152);
         k.full_step = env_long("MCMCPP_HIP_FULL_STEP", 1);
         k.full_step_max_walkers = env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", -1);
         k.task_table_mb = env_long("MCMCPP_HIP_TASK_TABLE_MB", 16);
@@ -337,12 +339,17 @@ public:
         // Matrix-core variants of the half-step kernel (dense calculators, fp64, even D in 18..32): the wavefront's
         // walkers are rows of one MFMA tile -- 8 walkers (2 passes) until the chip is full, 16 (4 passes) beyond.
         const long mc_min = knobs.matrix_core_min_walkers;
+        int mc_level = -1;  // matrix-core half-step kernel in use: 0 = 8 walkers per wavefront, 1 = 16, 2 = 16 with late draws
         if (table->half_step_mc[0][lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min &&
-            c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN)  // (they read the padded matrix this file prepares)
+            c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN &&     // (they read the padded matrix this file prepares)
+            (size_t)W * (size_t)D * sizeof(T) < (1ull << 32))  // (and address a chain's arrays with 32-bit byte offsets)
         {
-            const int big = launch_walkers >= knobs.matrix_core_4pass ? 1 : 0;
-            half_fn = table->half_step_mc[big][lpw_log][epl_shift];
-            passes = big ? 4 : 2;
+            mc_level = launch_walkers >= knobs.matrix_core_4pass ? 1 : 0;
+            // (about as many updates as one round of wavefront slots holds at three wavefronts per SIMD, or more: four per SIMD,
+            //  draws behind the accept -- profiles/r03_mc_threshold.txt)
+            if (mc_level == 1 && knobs.matrix_core_late >= 0 && launch_walkers >= knobs.matrix_core_late && table->half_step_mc[2][lpw_log][epl_shift]) mc_level = 2;
+            half_fn = table->half_step_mc[mc_level][lpw_log][epl_shift];
+            passes = mc_level == 0 ? 2 : 4;
             step_lpw = 16;  // (the matrix-core kernels map a walker to 16 lanes x 2 elements in either element type)
         }
 
@@ -354,7 +361,7 @@ public:
         const bool whole = shard_count == n && shard_begin == 0;
         // (measured, 32 dims fp64, us per ensemble step full / half: isotropic 32 768 walkers 7 % in favour of full steps;
         //  dense with the matrix-core half-step kernel 10.75 / 10.06 at 32 768, 5.47 / 7.28 at 16 384: profiles/r03_mc_probe_e.txt)
-        const bool mc_half = table->half_step_mc[0][lpw_log][epl_shift] && half_fn == table->half_step_mc[launch_walkers >= knobs.matrix_core_4pass ? 1 : 0][lpw_log][epl_shift];
+        const bool mc_half = mc_level >= 0;
         const long full_step_max = knobs.full_step_max_walkers >= 0 ? knobs.full_step_max_walkers : (mc_half ? 32767 : 32768);
         if ((c.comm_world >= 1 ? (knobs.comm_full_step != 0 && knobs.full_step != 0) : (whole && knobs.full_step != 0)) &&
             2 * launch_walkers <= full_step_max)

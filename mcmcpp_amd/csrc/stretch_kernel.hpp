@@ -1149,24 +1149,26 @@ __device__ __forceinline__ void mc_eval(const McB<T>& B, T* sx, int sub, int grp
     }
 }
 
-// P = passes per wavefront (2 or 4): the wavefront's 4*P walkers are rows 0..4P-1 of the 16-row tile.
-template <class T, class Calc, int EPL, int LPW, int P, bool DW, bool MC = false>
-#if MCMCPP_EXP_LEAN_FORCE4
-__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)), (P == 4 && !DW && sizeof(T) == 8) ? 4 : 1)
-#else
-__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)))
-#endif
+// P = passes per wavefront (2 or 4): the wavefront's 4 P walkers are rows 0 .. 4P-1 of the 16-row tile.
+// LATE (P = 4, no draw wavefront): the walkers' next draws are made BEHIND the accept instead of in the shadow of the partner
+// gather, which takes the jump entries and the 128-bit arithmetic out of the stretch where everything else is live -- 118
+// registers instead of 152 in fp64, four wavefronts per SIMD instead of three.  A launch is a whole number of rounds of the
+// chip's wavefront slots and a round is one latency chain (about 5 us) whatever it carries: 65 536 updates are 4 096
+// wavefronts of 16 walkers -- one round at four per SIMD, one and a third at three (measured as two: 10.7 against 12.9 us);
+// below 49 152 updates per launch the shorter wavefront wins (6.85 against 7.29 us at 32 768): the host picks by the size
+// of the launch (profiles/r03_mc_occupancy.txt, r03_mc_threshold.txt).
+template <class T, class Calc, int EPL, int LPW, int P, bool DW, bool MC = false, bool LATE = false>
+__global__ void __launch_bounds__(64 * (kWavesPerBlock + (DW ? 1 : 0)), (LATE && sizeof(T) == 8) ? 4 : 1)
 stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, int hot_n, uint32_t hot_bits,
                               int hot_shard_begin, int hot_shard_count, const StepCtl* hot_ctl_in, const T* hot_matrix, const HalfStepArgs<T> rest)
 {
     static_assert(EPL == 2 && LPW == 16, "matrix-core path: 16 lanes x 2 elements per walker, 16 < D <= 32");
     static_assert(P == 2 || P == 4, "two or four passes");
+    static_assert(!LATE || (P == 4 && !DW), "late draws: the 16-walker wavefront without a draw wavefront");
     constexpr int NW = 4 * P;   // walkers per wavefront
     constexpr int XS = kMcXS;
     constexpr int kStageRows = sizeof(T) == 8 ? NW : 16;  // rows of the tile that hold walkers (mc_row)
-    // LDS: proposal rows, NW x XS per wavefront.  The wavefront's share of P^T (zero-padded to 32 x 32 by the host) comes
-    // straight from memory into registers through a preloaded pointer, as in the full-step kernel: no LDS copy of the
-    // matrix, no workgroup barrier (hot_matrix is the sixteenth preloaded dword pair).
+    // LDS: proposal rows, kStageRows x XS per wavefront, then 32 x 32 elements for P^T (see kMatrixViaLds below).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* sh_x = reinterpret_cast<T*>(smem) + (threadIdx.x >> 6) * (kStageRows * XS);
 
@@ -1227,26 +1229,31 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     const int last_li = h_shard_count - 1;
 
     // ---- first round trip: draw records, own rows, log-posteriors, counters of all passes; the matrix ------------
+    // Addresses are the (uniform) array base plus a 32-bit byte offset per lane -- one register instead of two for each of
+    // the 5 P addresses a wavefront keeps until its stores (the host selects this kernel only for arrays below 4 GiB).
+    const char* const pos_b = reinterpret_cast<const char*>(h_pos);
+    const char* const logp_b = reinterpret_cast<const char*>(h_logp);
+    const char* const nacc_b = reinterpret_cast<const char*>(h_n_accept);
+    const char* const draws_b = reinterpret_cast<const char*>(h_draws);
     DrawRec<T> rec[P];
     T own[P][2];
     T lp_old[P];
-    uint32_t nacc_old[P];
     bool active[P];
-    int w[P];
+    uint32_t w[P];
 #pragma unroll
     for (int q = 0; q < P; ++q)
     {
         const int li = first + 4 * q + grp;
         active[q] = wave_active && li < h_shard_count;
-        w[q] = half_base + h_shard_begin + (active[q] ? li : 0);
-        rec[q] = h_draws[w[q] - half_base];
+        const uint32_t in_half = (uint32_t)(h_shard_begin + (active[q] ? li : 0));
+        w[q] = (uint32_t)half_base + in_half;
+        rec[q] = *reinterpret_cast<const DrawRec<T>*>(draws_b + in_half * (uint32_t)sizeof(DrawRec<T>));
         {
-            const V2 v = *reinterpret_cast<const V2*>(h_pos + (size_t)w[q] * h_dims + i0c);
+            const V2 v = *reinterpret_cast<const V2*>(pos_b + (w[q] * (uint32_t)h_dims + (uint32_t)i0c) * (uint32_t)sizeof(T));
             own[q][0] = (active[q] && col_ok) ? v.x : (T)0;
             own[q][1] = (active[q] && col_ok) ? v.y : (T)0;
         }
-        lp_old[q] = h_logp[w[q]];
-        nacc_old[q] = h_n_accept[w[q]];  // every lane of the group reads the same word: no divergent branch, no wait
+        lp_old[q] = *reinterpret_cast<const T*>(logp_b + w[q] * (uint32_t)sizeof(T));
     }
 
     const StepCtl* ctl_mine = hot_ctl_in;
@@ -1258,28 +1265,39 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     }
     const StepCtl ctl = *ctl_mine;
     const RunInfo run = *run_mine;
-    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;  // 3*NW lanes compute the walkers' next draws
-    const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);
+    // the walkers' 3 NW next draws, one per lane of the first 3 NW: in the shadow of the partner gather, or (LATE) behind
+    // the accept
+    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;
     const bool direct_jump = a.task_jump != nullptr;
     Affine128 j_a, j_b;
-    if constexpr (!DW)
-    {
-        if (direct_jump)
-            j_a = a.task_jump[3 * i_a + k_a];
-        else
-        {
-            j_a = a.jump_hi[i_a >> 8];
-            j_b = a.jump_lo[i_a & 255];
-        }
-    }
+    // (macros, not lambdas: a closure that captures the jump entries by reference keeps them in scratch memory)
+#define MCMCPP_LOAD_DRAW_JUMPS()                                                            \
+    do                                                                                      \
+    {                                                                                       \
+        const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);   \
+        if (direct_jump)                                                                    \
+            j_a = a.task_jump[3 * i_a + k_a];                                               \
+        else                                                                                \
+        {                                                                                   \
+            j_a = a.jump_hi[i_a >> 8];                                                      \
+            j_b = a.jump_lo[i_a & 255];                                                     \
+        }                                                                                   \
+    } while (0)
+#define MCMCPP_MAKE_NEXT_DRAWS()                                                                                                          \
+    do                                                                                                                                    \
+    {                                                                                                                                     \
+        if (lane < 3 * NW && first + slot_a < h_shard_count)                                                                              \
+            compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);                    \
+    } while (0)
+    if constexpr (!DW && !LATE) MCMCPP_LOAD_DRAW_JUMPS();
 
     // ---- second round trip: the partner rows of all passes ----------------------------------------------------------
     T par[P][2];
 #pragma unroll
     for (int q = 0; q < P; ++q)
     {
-        const int pw = other_base + (active[q] ? (int)rec[q].partner : 0);
-        const V2 v = *reinterpret_cast<const V2*>(h_pos + (size_t)pw * h_dims + i0c);
+        const uint32_t pw = (uint32_t)other_base + (active[q] ? rec[q].partner : 0u);
+        const V2 v = *reinterpret_cast<const V2*>(pos_b + (pw * (uint32_t)h_dims + (uint32_t)i0c) * (uint32_t)sizeof(T));
         par[q][0] = (active[q] && col_ok) ? v.x : (T)0;
         par[q][1] = (active[q] && col_ok) ? v.y : (T)0;
     }
@@ -1287,16 +1305,20 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // the partner gather so that it does not compete with the records the gather waits for
     asm volatile("" ::: "memory");
     McB<T> matB;
-#if MCMCPP_EXP_LEAN
-    // experiment: P^T through an LDS copy the workgroup's wavefronts fill behind their gathers (a barrier before the tile)
-    T* sh_pt = reinterpret_cast<T*>(smem) + kWavesPerBlock * (kStageRows * XS);
+    // P^T (zero-padded to 32 x 32 by the host, behind the sixteenth preloaded pointer).  With a draw wavefront in the
+    // workgroup every update wavefront fetches its share into registers (8 x 16 bytes per lane, the same 8 KiB for every
+    // wavefront: L2 hits).  Without one, the workgroup's four wavefronts fetch a quarter each, issued behind the partner
+    // gather, and share it through LDS behind a barrier that comes after the work done in the gather's shadow: a quarter
+    // of the L2 reads (8 KiB per 16 walkers was two thirds of the rows' own traffic) and 24 registers fewer where the
+    // pressure is highest (profiles/r03_lean_probe.txt).
+    constexpr bool kMatrixViaLds = !DW;
+    T* const sh_pt = reinterpret_cast<T*>(smem) + kWavesPerBlock * (kStageRows * XS);
     typedef T V4 __attribute__((ext_vector_type(4)));
     V4 mpiece;
-    if constexpr (!DW) mpiece = *reinterpret_cast<const V4*>(hot_matrix + 4 * threadIdx.x);
-    else mc_load_b(hot_matrix, sub, grp, matB);
-#else
-    mc_load_b(hot_matrix, sub, grp, matB);
-#endif
+    if constexpr (kMatrixViaLds)
+        mpiece = *reinterpret_cast<const V4*>(hot_matrix + 4 * threadIdx.x);
+    else
+        mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);  // records landed, partner gather issued
 
     // ---- in its shadow: hand-over to the next launch, the walkers' next draws ------------------------------------------
@@ -1304,29 +1326,13 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     // in the extra wavefront it would lengthen the last wavefront to finish: measured)
     if (blockIdx.x == 0 && threadIdx.x == 0)
         hand_over<T>(a, ctl, run, h_color, reinterpret_cast<StepCtl*>(reinterpret_cast<char*>(a.ctl_out) + (size_t)chain * kCtlChainStride));
-#if MCMCPP_EXP_LEAN
-    if constexpr (!DW)
-    {
-        *reinterpret_cast<V4*>(sh_pt + 4 * threadIdx.x) = mpiece;
-        __syncthreads();
-    }
-#endif
-    if (!wave_active) return;
     long long save_slot = -1;
     if (a.direct_save_slot >= 0)
         save_slot = a.direct_save_slot;
     else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
-    // Without a draw wavefront (16 walkers per wavefront) the walkers' next draws are made here, in the shadow of the
-    // gather.  (Behind the update instead -- fewer registers live across the tile, one more wavefront per SIMD -- the
-    // launch is 3 % shorter at 131 072 updates but 7 % longer at 65 536: profiles/r03_mc_probe_*.txt.)
-#if !MCMCPP_EXP_LEAN_NODRAW
-    if constexpr (!DW)
-    {
-        if (lane < 3 * NW && first + slot_a < h_shard_count)
-            compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);
-    }
-#endif
+    if constexpr (!DW && !LATE)
+        if (wave_active) MCMCPP_MAKE_NEXT_DRAWS();
     MCMCPP_STAMP(2);  // next draws done
 
     // ---- proposals (StretchMove.h:105-108) -----------------------------------------------------------------------
@@ -1346,11 +1352,16 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
 
     // ---- Y = X * P^T on the matrix cores, products and the canonical tree ------------------------------------------
     T lp_new[P];
-#if MCMCPP_EXP_LEAN
-    if constexpr (!DW) mc_load_b(sh_pt, sub, grp, matB);
-#endif
+    if constexpr (kMatrixViaLds)
+    {
+        *reinterpret_cast<V4*>(sh_pt + 4 * threadIdx.x) = mpiece;
+        __syncthreads();  // (every wavefront of the workgroup comes here, those without walkers too)
+        mc_load_b(sh_pt, sub, grp, matB);
+    }
+    if (!wave_active) return;
     mc_eval<P>(matB, sh_x, sub, grp, h_dims, prop, lp_new);
     MCMCPP_STAMP(4);  // calculator done
+    if constexpr (LATE) MCMCPP_LOAD_DRAW_JUMPS();
 
     // ---- Metropolis accept in place, chain store, counters ------------------------------------------------------------
     unsigned accepted_here = 0;
@@ -1366,24 +1377,31 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
             const T scale = dev_abs(ln_u) + dev_abs(zs) + dev_abs(lp_new[q]) + dev_abs(lp_old[q]);
             if (margin <= a.tie_eps * scale) count_near_tie(a.diag);
         }
-        T* row = h_pos + (size_t)w[q] * h_dims;
         if (accept)
         {
-            if (col_ok) *reinterpret_cast<V2*>(row + i0) = Vec2<T>::make(prop[q][0], prop[q][1]);
+            if (col_ok)
+                *reinterpret_cast<V2*>(const_cast<char*>(pos_b) + (w[q] * (uint32_t)h_dims + (uint32_t)i0) * (uint32_t)sizeof(T)) = Vec2<T>::make(prop[q][0], prop[q][1]);
             if (sub == 0)
             {
-                h_logp[w[q]] = lp_new[q];
-                h_n_accept[w[q]] = nacc_old[q] + 1u;
+                *reinterpret_cast<T*>(const_cast<char*>(logp_b) + w[q] * (uint32_t)sizeof(T)) = lp_new[q];
+                // (an add that returns nothing instead of a load in the first round trip and a store here: the counter is
+                //  this lane group's alone, and a register per pass is free while everything else is live)
+                __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(const_cast<char*>(nacc_b) + w[q] * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (save_slot >= 0 && active[q])
         {
             T* crow = reinterpret_cast<T*>(run.chain) + ((size_t)save_slot * (size_t)(2 * h_n) + (size_t)w[q]) * h_dims;
             if (col_ok)
-                *reinterpret_cast<V2*>(crow + i0) = accept ? Vec2<T>::make(prop[q][0], prop[q][1]) : Vec2<T>::make(own[q][0], own[q][1]);
+                // (a stored step is the exception: the row as it stands, from memory -- this lane's own store just above
+                //  included -- instead of registers kept for it across the tile)
+                *reinterpret_cast<V2*>(crow + i0) = *reinterpret_cast<const V2*>(pos_b + (w[q] * (uint32_t)h_dims + (uint32_t)i0) * (uint32_t)sizeof(T));
         }
         accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
     }
+    if constexpr (LATE) MCMCPP_MAKE_NEXT_DRAWS();
+#undef MCMCPP_LOAD_DRAW_JUMPS
+#undef MCMCPP_MAKE_NEXT_DRAWS
     MCMCPP_STAMP(5);
     MCMCPP_STAMP_BLOCK(1);
 #ifdef MCMCPP_STAMPS

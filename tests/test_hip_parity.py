@@ -210,6 +210,49 @@ def test_matrix_core_kernels_with_sixteen_walkers_per_wavefront_fp32(monkeypatch
     np.testing.assert_array_equal(pa, ha)
 
 
+@pytest.mark.parametrize("dtype", [po.F64, po.F32])
+@pytest.mark.parametrize("W,D,chains", [(8192 + 74, 32, 1), (2048 + 6, 26, 1), (1024 + 38, 32, 3)])
+def test_matrix_core_kernel_with_late_draws_four_wavefronts_per_simd(monkeypatch, W, D, chains, dtype):
+    """The 16-walker matrix-core half-step kernel in the form large launches get (MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS): next draws
+    behind the accept, 118 registers, four wavefronts per SIMD; P^T shared by the workgroup through LDS behind a barrier that
+    wavefronts without walkers reach too, the accepted counters by adds that return nothing, stored steps re-read from the
+    rows.  Ragged last wavefronts and workgroups, padded dimensions, several chains per launch, stored steps at an interval."""
+    monkeypatch.setenv("MCMCPP_HIP_FULL_STEP", "0")
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "0")
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", "1")
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS", "0")
+    if chains == 1:
+        orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, dtype, seed=11, steps=0)
+        oc, oa = orc.run(14, interval=2, mode=po.MODE_COUNTER, threads=4)
+        hc, ha = hip.run(14, interval=2)
+        np.testing.assert_array_equal(ha, oa)
+        np.testing.assert_array_equal(hc, oc)
+        _assert_same_state(orc, hip, ties_expected=dtype == po.F32)
+        return
+    t = po.np_dtype(dtype)
+    params = _params_for(po.CALC_DENSE_GAUSSIAN, D, t, np.random.default_rng(W + D))
+    orcs = []
+    for k in range(chains):
+        orc = po.Oracle(W, D, po.CALC_DENSE_GAUSSIAN, params, seed=11 + k, dtype=dtype)
+        pos = po.init_positions(dtype, W, D, salt=20 + k)
+        logp = orc.logp(pos)
+        orc.set_state(pos, logp)
+        orcs.append((orc, pos, logp))
+    hip = capi.HipSampler(W, D, po.CALC_DENSE_GAUSSIAN, params, seed=11, dtype=dtype, num_chains=chains)
+    hip.set_state(np.stack([o[1] for o in orcs]), np.stack([o[2] for o in orcs]))
+    hc, ha = hip.run(10, interval=2)
+    for k, (orc, _, _) in enumerate(orcs):
+        oc, oa = orc.run(10, interval=2, mode=po.MODE_COUNTER, threads=4)
+        np.testing.assert_array_equal(ha[k], oa, err_msg="chain %d" % k)
+        np.testing.assert_array_equal(hc[k], oc, err_msg="chain %d" % k)
+    pos, logp, nacc = hip.get_state()
+    for k, (orc, _, _) in enumerate(orcs):
+        opos, ologp, onacc = orc.get_state()
+        np.testing.assert_array_equal(pos[k], opos)
+        np.testing.assert_array_equal(logp[k], ologp)
+        np.testing.assert_array_equal(nacc[k], onacc)
+
+
 @pytest.mark.parametrize("batch", ["0", "1", "7", "128"])
 def test_draw_records_made_ahead_in_batches_of_any_length(monkeypatch, batch):
     """The matrix-core full-step launches of one whole ensemble read draw records made ahead by a launch of their own,

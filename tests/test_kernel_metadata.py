@@ -55,3 +55,10 @@ def test_step_kernels_carry_no_promoted_private_arrays_and_no_scratch(tmp_path):
     # the headline kernel keeps its one-workgroup-per-CU budget (8 wavefronts of 182 registers)
     head = [k for k in step if k["name"].startswith("stretch_full_step_mfma_kernel<double")]
     assert head and all(k["vgprs"] <= 192 for k in head), [(k["name"][:60], k["vgprs"]) for k in head]
+    # the 16-walker matrix-core half-step kernel: three wavefronts per SIMD with the next draws in the gather's shadow, four
+    # (LATE, the last template argument) with the draws behind the accept -- the point of the round-3 rework
+    mc16 = [k for k in step if re.match(r"stretch_half_step_mfma_kernel<double, DenseGaussianFn<double>, 2, 16, 4, false, (true|false), (true|false)>", k["name"])]
+    assert len(mc16) == 4, [k["name"][:100] for k in mc16]
+    for k in mc16:
+        late = k["name"].split(">(")[0].endswith("true")
+        assert k["vgprs"] <= (128 if late else 168), (k["name"][:100], k["vgprs"])
