@@ -201,7 +201,8 @@ de_update_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>
     load_slice<T, EPL>(hot_pos + (size_t)w * dims, i0, dims, vec_ok, active, own);
     const T lp_old = hot_logp[w];
     const uint32_t nacc_old = hot_n_accept[w];
-    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 : dims];
+    // (the jump to this lane's FIRST jitter, one draw beyond its first element's index: no step in front of it)
+    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 + 1 : dims];
     // the run record, field by field (needed behind the calculator: the loads have the whole launch to land)
     void* const run_chain = assume_global(hot_run->chain);
     const long long run_slot0 = hot_run->slot0;
@@ -242,7 +243,7 @@ de_update_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeRec<T>
 #pragma unroll
     for (int e = 0; e < EPL; ++e)
     {
-        su = pcg_step(su, a.inc);
+        if (e > 0) su = pcg_step(su, a.inc);
         const T u = canonical(pcg_output(su), T());
         jit[e] = a.jitter_low + (u * a.jitter_width);
     }
@@ -345,7 +346,10 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
         lp_old[q] = hot_logp[w[q]];
         nacc_old[q] = hot_n_accept[w[q]];
     }
-    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 : dims];
+    // the jump from the record's stream position to this lane's FIRST jitter (jump_small[j]: j draws; the table has more than
+    // D + 1 entries): a jump and one step per pass instead of a jump and two steps -- a 128-bit multiplication in three
+    // fewer; the update launch of a large ensemble is bound by its quarter-rate integer multiplies
+    const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 + 1 : dims];
     void* const run_chain = assume_global(hot_run->chain);
     const long long run_slot0 = hot_run->slot0;
     const uint32_t run_interval = hot_run->interval, run_phase0 = hot_run->phase0;
@@ -381,7 +385,7 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
 #pragma unroll
         for (int e = 0; e < 2; ++e)
         {
-            su = pcg_step(su, a.inc);
+            if (e > 0) su = pcg_step(su, a.inc);
             const T u = canonical(pcg_output(su), T());
             const T jit = a.jitter_low + (u * a.jitter_width);
             const T d = w1[q][e] - w2[q][e];
