@@ -1320,15 +1320,6 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     else
         mc_load_b(hot_matrix, sub, grp, matB);
     MCMCPP_STAMP(1);  // records landed, partner gather issued
-#if MCMCPP_EXP_NODRAW
-    // (timing experiment: the same records again next time instead of new ones)
-    if constexpr (LATE)
-    {
-#pragma unroll
-        for (int q = 0; q < P; ++q)
-            if (sub == 0 && active[q]) h_draws_next[w[q] - (uint32_t)half_base] = rec[q];
-    }
-#endif
 
     // ---- in its shadow: hand-over to the next launch, the walkers' next draws ------------------------------------------
     // one lane of the grid hands the stream and the counters to the next launch (in the shadow of its gather wait;
@@ -1370,9 +1361,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     if (!wave_active) return;
     mc_eval<P>(matB, sh_x, sub, grp, h_dims, prop, lp_new);
     MCMCPP_STAMP(4);  // calculator done
-#if !MCMCPP_EXP_NODRAW
     if constexpr (LATE) MCMCPP_LOAD_DRAW_JUMPS();
-#endif
 
     // ---- Metropolis accept in place, chain store, counters ------------------------------------------------------------
     unsigned accepted_here = 0;
@@ -1410,9 +1399,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         }
         accepted_here += (unsigned)__popcll(__ballot(accept && sub == 0));
     }
-#if !MCMCPP_EXP_NODRAW
     if constexpr (LATE) MCMCPP_MAKE_NEXT_DRAWS();
-#endif
 #undef MCMCPP_LOAD_DRAW_JUMPS
 #undef MCMCPP_MAKE_NEXT_DRAWS
     MCMCPP_STAMP(5);
