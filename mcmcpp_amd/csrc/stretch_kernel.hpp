@@ -1265,29 +1265,37 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     }
     const StepCtl ctl = *ctl_mine;
     const RunInfo run = *run_mine;
-    // the walkers' 3 NW next draws, one per lane of the first 3 NW: in the shadow of the partner gather, or (LATE) behind
-    // the accept
-    const int slot_a = lane / 3, k_a = lane - 3 * slot_a;
+    // The walkers' next draws, in the shadow of the partner gather or (LATE) behind the accept.  A wavefront of 16 walkers used
+    // to make its own 48 (lane l: draw l % 3 of walker l / 3) -- three kinds of arithmetic (partner index | z and (D-1) ln z |
+    // ln U) in one wavefront, run one after the other at a third of the lanes each.  The draws do not depend on the walkers,
+    // so the four wavefronts of a workgroup divide the workgroup's 64 walkers' draws BY KIND instead: three of them make one
+    // kind each for all 64 walkers (64 lanes, one path), the fourth makes none; the kind rotates with the workgroup so that no
+    // SIMD collects all the logarithms.  (Issue-bound kernel, profiles/r03_post_sq_breakdown_secondary.txt: two of three paths
+    // fewer per wavefront.)  Wavefronts without walkers of their own still make their share.
+    constexpr bool kDrawsByKind = !DW && NW * kWavesPerBlock == 64;
+    const int draw_kind = kDrawsByKind ? (int)(((threadIdx.x >> 6) + blockIdx.x) & 3u) : 0;
+    const int draw_first = kDrawsByKind ? (int)blockIdx.x * kWavesPerBlock * NW : first;
+    const int slot_a = kDrawsByKind ? lane : lane / 3, k_a = kDrawsByKind ? draw_kind : lane - 3 * slot_a;
+    const bool draws_here = kDrawsByKind ? (draw_kind < 3 && draw_first + slot_a < h_shard_count) : (wave_active && lane < 3 * NW && first + slot_a < h_shard_count);
     const bool direct_jump = a.task_jump != nullptr;
     Affine128 j_a, j_b;
     // (macros, not lambdas: a closure that captures the jump entries by reference keeps them in scratch memory)
-#define MCMCPP_LOAD_DRAW_JUMPS()                                                            \
-    do                                                                                      \
-    {                                                                                       \
-        const int i_a = h_shard_begin + (wave_active ? min(first + slot_a, last_li) : 0);   \
-        if (direct_jump)                                                                    \
-            j_a = a.task_jump[3 * i_a + k_a];                                               \
-        else                                                                                \
-        {                                                                                   \
-            j_a = a.jump_hi[i_a >> 8];                                                      \
-            j_b = a.jump_lo[i_a & 255];                                                     \
-        }                                                                                   \
+#define MCMCPP_LOAD_DRAW_JUMPS()                                                  \
+    do                                                                            \
+    {                                                                             \
+        const int i_a = h_shard_begin + max(min(draw_first + slot_a, last_li), 0); \
+        if (direct_jump)                                                          \
+            j_a = a.task_jump[3 * i_a + k_a];                                     \
+        else                                                                      \
+        {                                                                         \
+            j_a = a.jump_hi[i_a >> 8];                                            \
+            j_b = a.jump_lo[i_a & 255];                                           \
+        }                                                                         \
     } while (0)
-#define MCMCPP_MAKE_NEXT_DRAWS()                                                                                                          \
-    do                                                                                                                                    \
-    {                                                                                                                                     \
-        if (lane < 3 * NW && first + slot_a < h_shard_count)                                                                              \
-            compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + first + slot_a);                    \
+#define MCMCPP_MAKE_NEXT_DRAWS()                                                                                                                     \
+    do                                                                                                                                               \
+    {                                                                                                                                                \
+        if (draws_here) compute_draw<T>(a, ctl.state2, j_a, j_b, direct_jump, k_a, h_draws_next + h_shard_begin + draw_first + slot_a);              \
     } while (0)
     if constexpr (!DW && !LATE) MCMCPP_LOAD_DRAW_JUMPS();
 
@@ -1331,8 +1339,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         save_slot = a.direct_save_slot;
     else if (h_use_ctl_save && run.chain != nullptr && ctl.save_phase + 1u == (uint32_t)run.interval)
         save_slot = run.chain_slot_base + ctl.chain_slot;
-    if constexpr (!DW && !LATE)
-        if (wave_active) MCMCPP_MAKE_NEXT_DRAWS();
+    if constexpr (!DW && !LATE) MCMCPP_MAKE_NEXT_DRAWS();
     MCMCPP_STAMP(2);  // next draws done
 
     // ---- proposals (StretchMove.h:105-108) -----------------------------------------------------------------------
@@ -1358,7 +1365,15 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
         __syncthreads();  // (every wavefront of the workgroup comes here, those without walkers too)
         mc_load_b(sh_pt, sub, grp, matB);
     }
-    if (!wave_active) return;
+    if (!wave_active)
+    {
+        if constexpr (LATE && kDrawsByKind)
+        {
+            MCMCPP_LOAD_DRAW_JUMPS();
+            MCMCPP_MAKE_NEXT_DRAWS();
+        }
+        return;
+    }
     mc_eval<P>(matB, sh_x, sub, grp, h_dims, prop, lp_new);
     MCMCPP_STAMP(4);  // calculator done
     if constexpr (LATE) MCMCPP_LOAD_DRAW_JUMPS();
