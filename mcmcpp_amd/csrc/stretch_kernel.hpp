@@ -1285,7 +1285,7 @@ stretch_half_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos, T* hot_logp, ui
     {                                                                             \
         const int i_a = h_shard_begin + max(min(draw_first + slot_a, last_li), 0); \
         if (direct_jump)                                                          \
-            j_a = a.task_jump[3 * i_a + k_a];                                     \
+            j_a = a.task_jump[3 * i_a + min(k_a, 2)]; /* (the wavefront without draws: a valid entry) */ \
         else                                                                      \
         {                                                                         \
             j_a = a.jump_hi[i_a >> 8];                                            \
