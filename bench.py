@@ -712,7 +712,7 @@ def main():
                 secondary_config(capi, workloads, local_rank, "C4 on ONE GPU: 8 independent chains (seeds 0..7) of 16384 walkers x 32 dims, correlated "
                                  "Gaussian, StretchMove, fp64, stepped by the same launches (mcmcpp_hip_config.num_chains = 8); runs of 2000 "
                                  "ensemble steps, nothing stored", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
-                                 "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16>", 2000, chains=8, traffic_key="C4_one_gpu", seconds=args.secondary_seconds),
+                                 "stretch_half_step_mfma_kernel<double, DenseGaussianFn, EPL=2, LPW=16, P=4, several chains, late draws>", 2000, chains=8, traffic_key="C4_one_gpu", seconds=args.secondary_seconds),
                 secondary_config(capi, workloads, local_rank, "C2's target under the other ensemble mover (SURVEY 8f row f3): 16384 walkers x 32 dims, "
                                  "correlated Gaussian, Mover::DifferentialEvolution, fp64; runs of 2000 ensemble steps, nothing stored; the launch "
                                  "time includes the stream-planning launches", 16384, 32, capi.CALC_DENSE_GAUSSIAN, P.ravel(),
