@@ -361,6 +361,23 @@ __device__ __forceinline__ void store_row_piece(float* p, float x0, float x1)
     asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// The same stores addressed as (uniform base, 32-bit byte offset): one register per address, no 64-bit arithmetic
+__device__ __forceinline__ void store_row_piece_at(char* base, uint32_t off, double x0, double x1)
+{
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d v = {x0, x1};
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store_row_piece_at(char* base, uint32_t off, float x0, float x1)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f v = {x0, x1};
+    asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ void store_through_at(char* base, uint32_t off, uint32_t v) { asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
+__device__ __forceinline__ void store_through_at(char* base, uint32_t off, float v) { asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
+__device__ __forceinline__ void store_through_at(char* base, uint32_t off, double v) { asm volatile("global_store_dwordx2 %0, %1, %2 sc0 sc1" ::"v"(off), "v"(v), "s"(base) : "memory"); }
+
 template <class T, class Calc, int EPL, int LPW, bool MC = false>
 __global__ void __launch_bounds__(64 * (kWavesPerBlock + kFullDrawWaves))
 stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b, T* hot_logp_a, const T* hot_matrix, int hot_sh_begin, int hot_sh_count, int hot_n,
@@ -436,15 +453,29 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     // piece and idle groups re-read walker 0.  Their (finite) values only ever meet the zero padding of P^T (an fma
     // with +-0 leaves the chain untouched) or results that are never stored, and a load nobody masks is a load the
     // compiler has no reason to sink into a branch (which would serialise the round trip).
-    auto load_row = [&](const T* base, int w, T (&out)[2]) {
-        const V2 v = *reinterpret_cast<const V2*>(base + (size_t)w * h_dims + i0c);
+    // Addresses: (uniform array base, 32-bit byte offset) -- one register and one full-rate 24-bit multiply-add per row
+    // address instead of a 64-bit product and a 64-bit add; a dozen of them sit between the first round trip's arrival and
+    // the second's departure.  (The host takes this kernel only below 2^24 walkers and 4 GiB of rows.)
+    const char* const pin_b = reinterpret_cast<const char*>(pin);
+    const char* const lin_b = reinterpret_cast<const char*>(lin);
+    const char* const cnt_b = reinterpret_cast<const char*>(h_n_accept);
+    const char* const drr_b = reinterpret_cast<const char*>(dr_red);
+    const char* const drb_b = reinterpret_cast<const char*>(dr_blk);
+    char* const pout_b = reinterpret_cast<char*>(pout);
+    char* const lout_b = reinterpret_cast<char*>(lout);
+    const uint32_t un = (uint32_t)h_n;
+    auto row_off = [&](uint32_t w, int col) -> uint32_t { return (__umul24(w, (uint32_t)h_dims) + (uint32_t)col) * (uint32_t)sizeof(T); };
+    auto load_row = [&](uint32_t w, T (&out)[2]) {
+        const V2 v = *reinterpret_cast<const V2*>(pin_b + row_off(w, i0c));
         out[0] = v.x;
         out[1] = v.y;
     };
+    auto load_rec = [&](const char* base, uint32_t i) -> DrawRec<T> { return *reinterpret_cast<const DrawRec<T>*>(base + i * (uint32_t)sizeof(DrawRec<T>)); };
+    auto load_lp = [&](uint32_t w) -> T { return *reinterpret_cast<const T*>(lin_b + w * (uint32_t)sizeof(T)); };
 
     // ---- first round trip ----
     bool active[2];
-    int ir[2];
+    uint32_t ir[2];
     DrawRec<T> rec_r[2], rec_b[2];
     T own_r[2][2], own_b[2][2], lp_r[2], lp_b[2];
     uint32_t nacc_r[2], nacc_b[2];
@@ -453,15 +484,15 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     {
         const int li = first + 4 * q + grp;
         active[q] = li < sh_count;
-        ir[q] = sh_begin + (active[q] ? li : 0);
-        rec_r[q] = dr_red[ir[q]];
-        rec_b[q] = dr_blk[ir[q]];
-        load_row(pin, ir[q], own_r[q]);
-        load_row(pin, h_n + ir[q], own_b[q]);
-        lp_r[q] = lin[ir[q]];
-        lp_b[q] = lin[h_n + ir[q]];
-        nacc_r[q] = h_n_accept[ir[q]];
-        nacc_b[q] = h_n_accept[h_n + ir[q]];
+        ir[q] = (uint32_t)(sh_begin + (active[q] ? li : 0));
+        rec_r[q] = load_rec(drr_b, ir[q]);
+        rec_b[q] = load_rec(drb_b, ir[q]);
+        load_row(ir[q], own_r[q]);
+        load_row(un + ir[q], own_b[q]);
+        lp_r[q] = load_lp(ir[q]);
+        lp_b[q] = load_lp(un + ir[q]);
+        nacc_r[q] = *reinterpret_cast<const uint32_t*>(cnt_b + ir[q] * 4u);
+        nacc_b[q] = *reinterpret_cast<const uint32_t*>(cnt_b + (un + ir[q]) * 4u);
     }
 
     // ---- second round trip: everything the records point to ----
@@ -474,20 +505,20 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         // EXPERIMENT 3i (timing only, THE CHAIN IS WRONG): what a push scheme would read -- the rows the records point to
         // at addresses that follow from the walker's own index (an inbox of three rows per red/black pair), so that they
         // go out with the first round trip instead of behind it
-        const int bx = (3 * ir[q]) & (h_n - 1);
-        load_row(pin, h_n + bx, par_r[q]);
-        const int jx = (bx + 1) & (h_n - 1);
-        rec_x[q] = dr_red[jx];
-        load_row(pin, jx, own_x[q]);
-        lp_x[q] = lin[jx];
-        load_row(pin, h_n + ((bx + 2) & (h_n - 1)), par_x[q]);
+        const uint32_t bx = (3u * ir[q]) & (un - 1u);
+        load_row(un + bx, par_r[q]);
+        const uint32_t jx = (bx + 1u) & (un - 1u);
+        rec_x[q] = load_rec(drr_b, jx);
+        load_row(jx, own_x[q]);
+        lp_x[q] = load_lp(jx);
+        load_row(un + ((bx + 2u) & (un - 1u)), par_x[q]);
 #else
-        load_row(pin, h_n + (int)rec_r[q].partner, par_r[q]);
-        const int jx = (int)rec_b[q].partner;
-        rec_x[q] = dr_red[jx];
-        load_row(pin, jx, own_x[q]);
-        lp_x[q] = lin[jx];
-        load_row(pin, h_n + (int)rec_b[q].partner2, par_x[q]);
+        load_row(un + rec_r[q].partner, par_r[q]);
+        const uint32_t jx = rec_b[q].partner;
+        rec_x[q] = load_rec(drr_b, jx);
+        load_row(jx, own_x[q]);
+        lp_x[q] = load_lp(jx);
+        load_row(un + rec_b[q].partner2, par_x[q]);
 #endif
     }
     // The wavefront's share of P^T: 8 x 16 bytes per lane, the same 8 KiB for every wavefront (L2 hits), through a preloaded
@@ -523,15 +554,15 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
         lp_fin = accept ? lp_new : lp_old;
         return accept;
     };
-    auto commit = [&](int q, int w, const T (&fin)[2], T lp_fin, bool accept, uint32_t nacc_old) {
+    auto commit = [&](int q, uint32_t w, const T (&fin)[2], T lp_fin, bool accept, uint32_t nacc_old) {
         if (!active[q]) return;
         if (accept || (nacc_old & kRowMovedBit) != 0u)  // (otherwise `out` holds this row already)
         {
-            if (col_ok) store_row_piece(pout + (size_t)w * h_dims + i0, fin[0], fin[1]);
+            if (col_ok) store_row_piece_at(pout_b, row_off(w, i0), fin[0], fin[1]);
             if (sub == 0)
             {
-                store_through(lout + w, lp_fin);
-                store_through(h_n_accept + w, accept ? ((nacc_old + 1u) | kRowMovedBit) : (nacc_old & ~kRowMovedBit));
+                store_through_at(lout_b, w * (uint32_t)sizeof(T), lp_fin);
+                store_through_at(const_cast<char*>(cnt_b), w * 4u, accept ? ((nacc_old + 1u) | kRowMovedBit) : (nacc_old & ~kRowMovedBit));
             }
         }
         if (save_slot >= 0 && col_ok)
@@ -593,7 +624,7 @@ stretch_full_step_mfma_kernel(DrawRec<T>* hot_draws, T* hot_pos_a, T* hot_pos_b,
     for (int q = 0; q < 2; ++q)
     {
         const bool accb = decide(q, own_b[q], prop_b[q], rec_b[q], lp_b[q], lp_b_new[q], true, fin, lp_fin) && active[q];
-        commit(q, h_n + ir[q], fin, lp_fin, accb, nacc_b[q]);
+        commit(q, un + ir[q], fin, lp_fin, accb, nacc_b[q]);
 #if defined(MCMCPP_EXP_PUSH) && (MCMCPP_EXP_PUSH & 2)
         // EXPERIMENT 3i: the black walker's final row pushed to the two consumers it has on average
         if (a.stamps != nullptr && col_ok)

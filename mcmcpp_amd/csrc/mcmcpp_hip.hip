@@ -369,7 +369,8 @@ public:
             full_fn = table->full_step[lpw_log][epl_shift];
             full_wpb = kWavesPerBlock * (64 / lpw);
             if (table->full_step_mc[lpw_log][epl_shift] && (D % 2 == 0) && mc_min >= 0 && shard_count >= mc_min &&
-                c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN)  // (it reads the padded matrix this file prepares)
+                c.calc_id == MCMCPP_HIP_CALC_DENSE_GAUSSIAN &&  // (it reads the padded matrix this file prepares)
+                W < (1 << 24) && (size_t)W * (size_t)D * sizeof(T) < (1ull << 32))  // (and addresses rows by 24-bit products, 32-bit offsets)
             {
                 full_fn = table->full_step_mc[lpw_log][epl_shift];
                 full_wpb = kWavesPerBlock * 8;
