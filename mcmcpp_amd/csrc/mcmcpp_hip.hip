@@ -82,7 +82,7 @@ struct Knobs
     long passes;                  // MCMCPP_HIP_PASSES                   walkers-per-wavefront rounds of the half-step kernels (0: chosen from the size)
     long waves_per_simd;          // MCMCPP_HIP_WAVES_PER_SIMD           wavefronts per SIMD to reach before a wavefront takes more walkers (2)
     long matrix_core_min_walkers; // MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS  smallest shard stepped by the matrix-core kernels (0; -1: never)
-    long matrix_core_4pass;       // MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS from this many walkers per half on: 16 walkers per wavefront (32768)
+    long matrix_core_4pass;       // MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS from this many updates per launch on: 16 walkers per wavefront (18432)
     long matrix_core_late;        // MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS    from this many updates per launch on: the 16-walker wavefronts make their next draws behind the accept, four to a SIMD (49152; -1: never)
     long full_step;               // MCMCPP_HIP_FULL_STEP                1: one launch per ensemble step for small ensembles (1)
     long full_step_max_walkers;   // MCMCPP_HIP_FULL_STEP_MAX_WALKERS    largest ensemble stepped that way (-1: 32768; 32767 where the matrix-core
@@ -109,7 +109,9 @@ struct Knobs
         k.passes = env_long("MCMCPP_HIP_PASSES", 0);
         k.waves_per_simd = env_long("MCMCPP_HIP_WAVES_PER_SIMD", 2);
         k.matrix_core_min_walkers = env_long("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", 0);
-        k.matrix_core_4pass = env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 32768);
+        // (measured after the round-3 rework, us per launch with 8 / 16 walkers per wavefront: 16 384 updates 5.04 / 5.23,
+        //  20 480: 7.37 / 6.57, 24 576: 7.54 / 6.63, 28 672: 9.97 / 6.72, 32 768: 10.02 / 6.78 -- profiles/r03_mc_p2_p4.txt)
+        k.matrix_core_4pass = env_long("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", 18432);
         k.matrix_core_late = env_long("MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS", 49152);
         k.full_step = env_long("MCMCPP_HIP_FULL_STEP", 1);
         k.full_step_max_walkers = env_long("MCMCPP_HIP_FULL_STEP_MAX_WALKERS", -1);
