@@ -210,17 +210,20 @@ def test_matrix_core_kernels_with_sixteen_walkers_per_wavefront_fp32(monkeypatch
     np.testing.assert_array_equal(pa, ha)
 
 
+@pytest.mark.parametrize("late", ["0", "-1"])
 @pytest.mark.parametrize("dtype", [po.F64, po.F32])
 @pytest.mark.parametrize("W,D,chains", [(8192 + 74, 32, 1), (2048 + 6, 26, 1), (1024 + 38, 32, 3)])
-def test_matrix_core_kernel_with_late_draws_four_wavefronts_per_simd(monkeypatch, W, D, chains, dtype):
+def test_matrix_core_kernel_with_late_draws_four_wavefronts_per_simd(monkeypatch, W, D, chains, dtype, late):
     """The 16-walker matrix-core half-step kernel in the form large launches get (MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS): next draws
     behind the accept, 118 registers, four wavefronts per SIMD; P^T shared by the workgroup through LDS behind a barrier that
     wavefronts without walkers reach too, the accepted counters by adds that return nothing, stored steps re-read from the
-    rows.  Ragged last wavefronts and workgroups, padded dimensions, several chains per launch, stored steps at an interval."""
+    rows, the workgroup's next draws divided by kind among its wavefronts (those without walkers make their share).  Ragged
+    last wavefronts and workgroups, padded dimensions, several chains per launch, stored steps at an interval.  late = "-1":
+    the same kernel with the draws in the gather's shadow (what launches of 18 432 .. 49 151 updates take)."""
     monkeypatch.setenv("MCMCPP_HIP_FULL_STEP", "0")
     monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_MIN_WALKERS", "0")
     monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_4PASS_WALKERS", "1")
-    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS", "0")
+    monkeypatch.setenv("MCMCPP_HIP_MATRIX_CORE_LATE_DRAWS", late)
     if chains == 1:
         orc, hip = _oracle_and_hip(W, D, po.CALC_DENSE_GAUSSIAN, dtype, seed=11, steps=0)
         oc, oa = orc.run(14, interval=2, mode=po.MODE_COUNTER, threads=4)
