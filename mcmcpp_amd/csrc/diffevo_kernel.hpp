@@ -166,6 +166,33 @@ __host__ __device__ inline uint32_t de_hot_bits(int dims, int color, int vec_ok,
     return (uint32_t)dims | ((uint32_t)color << 12) | ((uint32_t)vec_ok << 14) | ((uint32_t)step << 16);
 }
 
+// The run record and the two lines of the launch description (kernarg) that hold DeArgs, in ONE batch of scalar loads with
+// one wait -- called behind the first round trip's vector loads, where the wait is free.  Left to the compiler these are cold
+// scalar misses issued where a field is first needed: behind the partner gather, with a wait that the matrix loads and the
+// jitter arithmetic then sit behind (see load_records_and_warm_args in stretch_kernel.hpp; the kernels' argument lists are
+// 64 bytes of preloaded hot arguments followed by the DeArgs).
+template <class T>
+__device__ __forceinline__ DeRunInfo de_load_run_and_warm_args(const DeRunInfo* run_ptr)
+{
+    static_assert(sizeof(DeRunInfo) == 64 && 64 + sizeof(DeArgs<T>) <= 0xc0, "one s_load_dwordx16; adjust the lines touched below");
+    typedef unsigned v16u __attribute__((ext_vector_type(16)));
+    const unsigned long long k = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned long long v = (unsigned long long)run_ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const unsigned long long run_addr = ((unsigned long long)hi << 32) | lo;
+    v16u r;
+    unsigned t1, t2;
+    asm volatile(
+        "s_load_dwordx16 %0, %3, 0x0\n\t"
+        "s_load_dword %1, %4, 0x40\n\t"
+        "s_load_dword %2, %4, 0x80\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(r), "=&s"(t1), "=&s"(t2)
+        : "s"(run_addr), "s"(k)
+        : "memory");
+    return __builtin_bit_cast(DeRunInfo, r);
+}
+
 // ---- the update of one half-step ----------------------------------------------------------------------------------------
 // The hot_* arguments are what an updating wavefront needs before its second round trip; they travel in the 16 dwords
 // the command processor preloads into SGPRs (see HotBits in stretch_kernel.hpp), everything else in `a`.
@@ -350,9 +377,24 @@ de_update_mfma_kernel(T* hot_pos, T* hot_logp, uint32_t* hot_n_accept, const DeR
     // D + 1 entries): a jump and one step per pass instead of a jump and two steps -- a 128-bit multiplication in three
     // fewer; the update launch of a large ensemble is bound by its quarter-rate integer multiplies
     const Affine128 j_uni = hot_jump_small[i0 < dims ? i0 + 1 : dims];
-    void* const run_chain = assume_global(hot_run->chain);
-    const long long run_slot0 = hot_run->slot0;
-    const uint32_t run_interval = hot_run->interval, run_phase0 = hot_run->phase0;
+    // The run record and the launch description's cold lines: in one batch of scalar loads behind the vector loads above for
+    // the 8-walker wavefronts of small, latency-bound launches (C2's half-step 4.95 -> 4.66 us: left to the compiler the
+    // kernarg miss sits behind the partner gather, in front of the matrix loads and the jitter arithmetic); field by field,
+    // where first needed, for the 16-walker wavefronts of large ones, where the early wait costs more than it saves
+    // (262 144 walkers: 30.3 against 30.9 us; profiles/r03_de_warm.txt).
+    DeRunInfo run_rec;
+    if constexpr (P == 2)
+        run_rec = de_load_run_and_warm_args<T>(hot_run);
+    else
+    {
+        run_rec.chain = hot_run->chain;
+        run_rec.slot0 = hot_run->slot0;
+        run_rec.interval = hot_run->interval;
+        run_rec.phase0 = hot_run->phase0;
+    }
+    void* const run_chain = assume_global(run_rec.chain);
+    const long long run_slot0 = run_rec.slot0;
+    const uint32_t run_interval = run_rec.interval, run_phase0 = run_rec.phase0;
 
     // second round trip: the two partner rows of every pass
     T w1[P][2], w2[P][2];
